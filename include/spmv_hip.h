@@ -1,0 +1,177 @@
+/*
+ * libspmv_hip -- C ABI of the MI355X (gfx950) SpMV engine.
+ *
+ * Drop-in boundary for the reference's create_X / mult_X / free_X plugin
+ * interface (reference src/spmv.h, src/sellp.h) as selected by its driver
+ * (reference src/driver_spmv.c:186-261).  Plain pointers and sizes only.
+ *
+ * Conventions
+ *   - Every function returning `int` returns 0 on success, non-zero on error;
+ *     creators return NULL on error.  spmv_hip_last_error() gives the message
+ *     (the reference prints to stderr and exit()s instead: mtx.c:39-41,
+ *     spmv.h:277-281; the C driver in spmv_amd/csrc/driver keeps that
+ *     behaviour on top of these status codes).
+ *   - `dtype`: SPMV_HIP_F64 computes like the reference (double storage and
+ *     accumulation); SPMV_HIP_F32 stores and accumulates in float (the
+ *     reference has no float path).
+ *   - Overwrite semantics for y in every format (the driver pre-fills y with
+ *     garbage, driver_spmv.c:269), never writing past `rows`.
+ *   - One host thread drives a handle; calls on one handle are ordered on the
+ *     stream they are given.
+ */
+#ifndef SPMV_HIP_H
+#define SPMV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* reference src/spmv.h:26 -- AoS COO entry, 0-based */
+#ifndef SPMV_HIP_NO_MTX_STRUCT
+struct mtx { int i; int j; double a; };
+#endif
+
+typedef struct spmv_hip_matrix spmv_hip_matrix;
+
+enum { SPMV_HIP_F64 = 0, SPMV_HIP_F32 = 1 };
+
+/* storage format + kernel of a handle */
+enum {
+    SPMV_HIP_CSR_SCALAR = 0,  /* one lane per row                    (mult_csr_base,  csr.c:4-13)   */
+    SPMV_HIP_CSR_VECTOR = 1,  /* 2..64 lanes per row, wave reduction (mult_csr,       csr.c:124-150) */
+    SPMV_HIP_CSR_MERGE  = 2,  /* merge-path tiles, LDS-staged        (spmvmCRSMerge,  csr_merge.c:15-59) */
+    SPMV_HIP_CSR_BAL    = 3,  /* nnz-balanced tiles, LDS-staged      (mult_csr_bal,   csr_bal.c:3-38) */
+    SPMV_HIP_SELL       = 4,  /* SELL-C-sigma                        (mult_sell,      sell.c:35-42)  */
+    SPMV_HIP_SELLP      = 5,  /* sliced ELL, natural row order       (mult_sellp,     sellp.c:304-342) */
+    SPMV_HIP_ELL        = 6   /* sliced ELL, natural row order       (mult_ell,       ell.c:28-45)   */
+};
+
+/* arrays that spmv_hip_download() can read back (layout parity tests) */
+enum {
+    SPMV_HIP_ARR_ROW_PTR    = 0,  /* int32  [rows+1]            CSR family                       */
+    SPMV_HIP_ARR_COL        = 1,  /* int32  [stored]            CSR col / sliced column_indices  */
+    SPMV_HIP_ARR_VAL        = 2,  /* dtype  [stored]            CSR val / sliced values          */
+    SPMV_HIP_ARR_SLICE_PTR  = 3,  /* int64  [nslices+1]         sliced formats (slice_pointers / block_ptr) */
+    SPMV_HIP_ARR_ROW_ORDER  = 4,  /* int32  [rows]              SELL only (row_order)            */
+    SPMV_HIP_ARR_TILE_COORD = 5   /* int32  [2*(ntiles+1)]      merge: (row,nnz) start of each tile; bal: (compact row, nnz) */
+};
+
+typedef struct spmv_hip_info {
+    int     format, dtype;
+    int     rows, columns;
+    int64_t nnz;          /* true non-zeros (what GFLOP/s counts, driver_spmv.c:307) */
+    int64_t stored;       /* entries held in HBM incl. padding                        */
+    int     slice_height; /* C (SELL) / block height (SELLP, ELL); 0 otherwise        */
+    int64_t sigma;        /* SELL sorting window; 0 otherwise                         */
+    int     nslices;      /* sliced formats; 0 otherwise                              */
+    int     lanes_per_row;/* CSR_VECTOR group size; 1 for CSR_SCALAR; 0 otherwise     */
+    int     ntiles;       /* CSR_MERGE / CSR_BAL workgroup tiles; 0 otherwise         */
+    int     items_per_tile;
+    int64_t device_bytes; /* HBM held by the handle                                   */
+} spmv_hip_info;
+
+/* Selects the device for subsequent creators on this thread (hipSetDevice). */
+int spmv_hip_init(int device);
+/* Message of the last failing call on this thread ("" if none). */
+const char *spmv_hip_last_error(void);
+
+/* ---- host-side ingest (reference mtx.c) ---------------------------------------
+ * load_mtx (mtx.c:36-137): MatrixMarket coordinate real/integer/pattern,
+ * general or mirrored symmetry, 1-based -> 0-based, explicit zeros dropped.
+ * Returns non-zero (with a message) where the reference prints and exit(1)s.
+ * *coo is malloc'ed; release it with spmv_hip_free_coo. */
+int spmv_hip_load_mtx(const char *fname, int *rows, int *columns, int *nnz, struct mtx **coo);
+void spmv_hip_free_coo(struct mtx *coo);
+/* sort_mtx(nnz, coo, by_row_mtx) (mtx.c:9-34): (row, col) order, in place,
+ * untouched if already sorted. */
+void spmv_hip_sort_coo(int nnz, struct mtx *coo);
+
+/* ---- creators from a host COO (reference spmv.h:50,98,118,135) --------------
+ * Like the reference creators these sort the caller's coo IN PLACE by
+ * (row, col) (mtx.c:18-34) -- the driver's COO check (driver_spmv.c:274)
+ * depends on that side effect -- and do not keep a pointer to it. */
+
+/* create_csr (spmv.h:50, csr.c:160-203): `alignment` > 1 pads every row with
+ * (j=0, A=0) to a multiple of it.  `kernel` is SPMV_HIP_CSR_SCALAR or
+ * SPMV_HIP_CSR_VECTOR; `lanes_per_row` 0 = choose from the mean row length. */
+spmv_hip_matrix *spmv_hip_create_csr(int rows, int columns, int nnz, int alignment,
+                                     struct mtx *coo, int dtype, int kernel, int lanes_per_row);
+/* create_csr_merge (spmv.h:98, csr_merge.c:87-115).  The reference freezes
+ * nthreads at create time (csr_merge.c:93); here the tile size plays that
+ * role: items_per_tile 0 = default. */
+spmv_hip_matrix *spmv_hip_create_csr_merge(int rows, int columns, int nnz, struct mtx *coo,
+                                           int dtype, int items_per_tile);
+/* create_csr_bal (spmv.h:118, csr_bal.c:66-94): equal-nnz chunks, one per
+ * workgroup; nnz_per_tile 0 = default.  Unlike the reference (csr_bal.c:29)
+ * matrices with empty rows are handled. */
+spmv_hip_matrix *spmv_hip_create_csr_bal(int rows, int columns, int nnz, struct mtx *coo,
+                                         int dtype, int nnz_per_tile);
+/* create_ell (spmv.h:135, ell.c:48-112): sliced ELL in natural row order.
+ * slice_height 0 = 64 (one wave64 per slice); 4 reproduces the reference's
+ * SIMD_WIDTH (ell.c:4).  Column indices are 32-bit in HBM (the reference's
+ * int64 j, spmv.h:131, is a host-side choice; values are identical). */
+spmv_hip_matrix *spmv_hip_create_ell(int rows, int columns, int nnz, struct mtx *coo,
+                                     int dtype, int slice_height);
+
+/* ---- creators from host CSR arrays ----------------------------------------- */
+
+/* create_sellp (sellp.h:15, sellp.c:352-458): slice_height 0 = 64; the
+ * reference's _BLOCK is 2/4/8 (spmv.h:8-23). */
+spmv_hip_matrix *spmv_hip_create_sellp(int rows, int columns, int nnz, const int *row_ptr,
+                                       const int *col, const double *A, int dtype, int slice_height);
+/* create_sell (spmv.h:233, sell.c:8-33) with the struct csr flattened.
+ * C 0 = 64 (sell.c:5); sigma 0 = 16384 (sell.c:4).  sigma must be a multiple
+ * of C (otherwise the reference's "first row of the slice is the longest"
+ * rule, sellcs_format.c:152-158, does not hold) and at most 32768. */
+spmv_hip_matrix *spmv_hip_create_sell(int rows, int columns, int nnz, const int *row_ptr,
+                                      const int *col, const double *A, int dtype, int C, int64_t sigma);
+
+/* ---- creator from CSR arrays already resident in HBM ------------------------
+ * For matrices generated on the device.  d_val is float or double per `dtype`.
+ * The CSR arrays are adopted by reference for the CSR family (the caller keeps
+ * them alive until spmv_hip_free) and only read for the sliced formats.
+ * p0/p1: CSR_VECTOR lanes_per_row / -; CSR_MERGE items_per_tile / -; CSR_BAL
+ * nnz_per_tile / -; SELL C / sigma; SELLP, ELL slice_height / -.  0 = default.
+ * No reference counterpart (the reference has no device). */
+spmv_hip_matrix *spmv_hip_create_from_device_csr(int format, int rows, int columns, int64_t nnz,
+                                                 const int *d_row_ptr, const int *d_col, const void *d_val,
+                                                 int dtype, int64_t p0, int64_t p1, void *stream);
+
+/* ---- multiply --------------------------------------------------------------- */
+
+/* mult_X(matrix, x, y) (driver_spmv.c:184,276): host vectors, x[columns],
+ * y[rows]; copies x up, runs the kernel, copies y back.  Drop-in, PCIe-bound. */
+int spmv_hip_mult(spmv_hip_matrix *m, const double *x, double *y);
+/* Same product with x and y resident in HBM (dtype elements) on `stream`
+ * (a hipStream_t; NULL = default stream).  Asynchronous. */
+int spmv_hip_mult_dev(spmv_hip_matrix *m, const void *d_x, void *d_y, void *stream);
+
+/* free_X (csr.c:205-210, sellp.c:461-465; the reference leaks the others) */
+int spmv_hip_free(spmv_hip_matrix *m);
+
+/* ---- measurement (driver_spmv.c:292-308) ------------------------------------
+ * Power-iteration loop with x, y resident: each iteration times one multiply
+ * with HIP events, then x = y / ||y||_2 untimed, until iterations >= min_iters
+ * and wall time > min_seconds.  x (host, columns doubles) is the start vector
+ * and receives the last iterate.  rows must equal columns. */
+int spmv_hip_bench(spmv_hip_matrix *m, int min_iters, double min_seconds, double *x,
+                   int *iters, double *seconds);
+
+/* ---- vector helpers on device (driver_spmv.c:21-26, 301-302) ---------------- */
+/* *d_out (double, device) = ||d_x||_2 ; deterministic two-pass reduction */
+int spmv_hip_norm2_dev(int n, const void *d_x, int dtype, double *d_out, void *stream);
+/* d_x[i] = d_y[i] / *d_norm */
+int spmv_hip_scale_dev(int n, const void *d_y, void *d_x, int dtype, const double *d_norm, void *stream);
+
+/* ---- introspection for layout-parity tests ---------------------------------- */
+int spmv_hip_get_info(const spmv_hip_matrix *m, spmv_hip_info *info);
+/* Copies one device array to host; `bytes` must equal the array's size. */
+int spmv_hip_download(const spmv_hip_matrix *m, int which, void *host, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPMV_HIP_H */

@@ -1,0 +1,84 @@
+"""ctypes binding of libspmv_hip.so (the C ABI declared in include/spmv_hip.h).
+
+There is no fallback: if the library has not been built, importing a symbol
+raises.  Build it with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C spmv_amd/csrc`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspmv_hip.so")
+
+F64, F32 = 0, 1
+CSR_SCALAR, CSR_VECTOR, CSR_MERGE, CSR_BAL, SELL, SELLP, ELL = range(7)
+ARR_ROW_PTR, ARR_COL, ARR_VAL, ARR_SLICE_PTR, ARR_ROW_ORDER, ARR_TILE_COORD = range(6)
+
+FORMAT_NAMES = {CSR_SCALAR: "csr_scalar", CSR_VECTOR: "csr_vector", CSR_MERGE: "csr_merge",
+                CSR_BAL: "csr_bal", SELL: "sell", SELLP: "sellp", ELL: "ell"}
+
+
+class Info(C.Structure):
+    _fields_ = [("format", C.c_int), ("dtype", C.c_int), ("rows", C.c_int), ("columns", C.c_int),
+                ("nnz", C.c_int64), ("stored", C.c_int64), ("slice_height", C.c_int),
+                ("sigma", C.c_int64), ("nslices", C.c_int), ("lanes_per_row", C.c_int),
+                ("ntiles", C.c_int), ("items_per_tile", C.c_int), ("device_bytes", C.c_int64)]
+
+
+# name -> (restype, argtypes); every symbol include/spmv_hip.h declares
+_vp, _i, _i64 = C.c_void_p, C.c_int, C.c_int64
+SIGNATURES = {
+    "spmv_hip_init": (_i, [_i]),
+    "spmv_hip_last_error": (C.c_char_p, []),
+    "spmv_hip_load_mtx": (_i, [C.c_char_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_vp)]),
+    "spmv_hip_free_coo": (None, [_vp]),
+    "spmv_hip_sort_coo": (None, [_i, _vp]),
+    "spmv_hip_create_csr": (_vp, [_i, _i, _i, _i, _vp, _i, _i, _i]),
+    "spmv_hip_create_csr_merge": (_vp, [_i, _i, _i, _vp, _i, _i]),
+    "spmv_hip_create_csr_bal": (_vp, [_i, _i, _i, _vp, _i, _i]),
+    "spmv_hip_create_ell": (_vp, [_i, _i, _i, _vp, _i, _i]),
+    "spmv_hip_create_sellp": (_vp, [_i, _i, _i, _vp, _vp, _vp, _i, _i]),
+    "spmv_hip_create_sell": (_vp, [_i, _i, _i, _vp, _vp, _vp, _i, _i, _i64]),
+    "spmv_hip_create_from_device_csr": (_vp, [_i, _i, _i, _i64, _vp, _vp, _vp, _i, _i64, _i64, _vp]),
+    "spmv_hip_mult": (_i, [_vp, _vp, _vp]),
+    "spmv_hip_mult_dev": (_i, [_vp, _vp, _vp, _vp]),
+    "spmv_hip_free": (_i, [_vp]),
+    "spmv_hip_bench": (_i, [_vp, _i, C.c_double, _vp, C.POINTER(_i), C.POINTER(C.c_double)]),
+    "spmv_hip_norm2_dev": (_i, [_i, _vp, _i, _vp, _vp]),
+    "spmv_hip_scale_dev": (_i, [_i, _vp, _vp, _i, _vp, _vp]),
+    "spmv_hip_get_info": (_i, [_vp, C.POINTER(Info)]),
+    "spmv_hip_download": (_i, [_vp, _i, _vp, C.c_size_t]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library.  Raises OSError if libspmv_hip.so is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OSError(f"{LIB_PATH} not built (make -C spmv_amd/csrc); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+class SpmvHipError(RuntimeError):
+    pass
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise SpmvHipError(lib().spmv_hip_last_error().decode())
+
+
+def check_handle(h):
+    if not h:
+        raise SpmvHipError(lib().spmv_hip_last_error().decode())
+    return h

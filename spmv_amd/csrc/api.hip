@@ -1,0 +1,423 @@
+// C ABI of libspmv_hip: creators, multiply, free, bench loop, introspection.
+
+#include "internal.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace spmv {
+
+static thread_local char g_error[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof g_error, fmt, ap);
+    va_end(ap);
+}
+void clear_error() { g_error[0] = 0; }
+
+static void sort_coo_in_place(int64_t nnz, struct mtx *coo) { spmv_hip_sort_coo((int)nnz, coo); }
+
+// COO (sorted) -> CSR with optional per-row padding to a multiple of
+// `alignment` using (j=0, A=0) entries (reference csr.c:160-203).
+static int coo_to_csr(int rows, int64_t nnz, int alignment, const struct mtx *coo, std::vector<int> &rp,
+                      std::vector<int> &cj, std::vector<double> &va)
+{
+    if (alignment < 1) { set_error("alignment %d < 1", alignment); return 1; }
+    rp.assign((size_t)rows + 1, 0);
+    for (int64_t l = 0; l < nnz; l++) {
+        if (coo[l].i < 0 || coo[l].i >= rows) { set_error("coo[%lld].i = %d out of range", (long long)l, coo[l].i); return 1; }
+        rp[(size_t)coo[l].i + 1]++;
+    }
+    int64_t p = 0;
+    for (int r = 0; r < rows; r++) {
+        int64_t len = rp[(size_t)r + 1];
+        int64_t padded = (len + alignment - 1) / alignment * alignment;
+        // the reference pads the running total, which equals per-row padding
+        // because every earlier row already ends on a multiple
+        p += padded;
+        if (p > 0x7fffffffLL) { set_error("padded nnz exceeds 2^31-1"); return 1; }
+        rp[(size_t)r + 1] = (int)p;
+    }
+    cj.assign((size_t)p, 0);
+    va.assign((size_t)p, 0.0);
+    int64_t l = 0;
+    for (int r = 0; r < rows; r++) {
+        int64_t w = rp[r];
+        while (l < nnz && coo[l].i == r) { cj[(size_t)w] = coo[l].j; va[(size_t)w] = coo[l].a; w++; l++; }
+    }
+    return 0;
+}
+
+static int check_dims(int rows, int columns, int64_t nnz, int dtype)
+{
+    if (rows < 0 || columns < 0 || nnz < 0) { set_error("negative dimension"); return 1; }
+    if (dtype != SPMV_HIP_F64 && dtype != SPMV_HIP_F32) { set_error("unknown dtype %d", dtype); return 1; }
+    return 0;
+}
+
+static int check_columns(int columns, const std::vector<int> &cj)
+{
+    for (size_t k = 0; k < cj.size(); k++)
+        if (cj[k] < 0 || cj[k] >= std::max(columns, 1)) { set_error("column index %d out of range at entry %zu", cj[k], k); return 1; }
+    return 0;
+}
+
+static spmv_hip_matrix *new_handle(int format, int dtype, int rows, int columns, int64_t nnz)
+{
+    spmv_hip_matrix *m = new (std::nothrow) spmv_hip_matrix();
+    if (!m) { set_error("out of host memory"); return nullptr; }
+    m->format = format; m->dtype = dtype; m->rows = rows; m->columns = columns; m->nnz = nnz;
+    if (hipGetDevice(&m->device) != hipSuccess) { set_error("no HIP device available"); delete m; return nullptr; }
+    return m;
+}
+
+// Upload host CSR (double values) into the handle, converting to the handle's dtype.
+static int upload_csr(spmv_hip_matrix *m, const std::vector<int> &rp, const std::vector<int> &cj,
+                      const std::vector<double> &va, bool keep_f64_values)
+{
+    m->stored = (int64_t)cj.size();
+    m->owns_csr = true;
+    if (dev_alloc(m, &m->d_row_ptr, rp.size())) return 1;
+    if (dev_alloc(m, &m->d_col, cj.size())) return 1;
+    SPMV_HIP_TRY(hipMemcpy(m->d_row_ptr, rp.data(), sizeof(int) * rp.size(), hipMemcpyHostToDevice), return 1);
+    if (!cj.empty()) SPMV_HIP_TRY(hipMemcpy(m->d_col, cj.data(), sizeof(int) * cj.size(), hipMemcpyHostToDevice), return 1);
+    if (m->dtype == SPMV_HIP_F64 || keep_f64_values) {
+        if (dev_alloc(m, (double **)&m->d_val, va.size())) return 1;
+        if (!va.empty()) SPMV_HIP_TRY(hipMemcpy(m->d_val, va.data(), sizeof(double) * va.size(), hipMemcpyHostToDevice), return 1);
+    } else {
+        std::vector<float> vf(va.begin(), va.end());
+        if (dev_alloc(m, (float **)&m->d_val, vf.size())) return 1;
+        if (!vf.empty()) SPMV_HIP_TRY(hipMemcpy(m->d_val, vf.data(), sizeof(float) * vf.size(), hipMemcpyHostToDevice), return 1);
+    }
+    return 0;
+}
+
+static void release_csr(spmv_hip_matrix *m)
+{
+    if (m->owns_csr) {
+        if (m->d_row_ptr) (void)hipFree(m->d_row_ptr);
+        if (m->d_col) (void)hipFree(m->d_col);
+        if (m->d_val) (void)hipFree(m->d_val);
+    }
+    m->d_row_ptr = nullptr; m->d_col = nullptr; m->d_val = nullptr;
+}
+
+static int normalize_tile_param(int64_t p, int dflt, int *out)
+{
+    int v = p == 0 ? dflt : (int)p;
+    const int ok[] = {4, 7, 8, 12, 16};
+    for (int k : ok)
+        if (v == k * kBlock) { *out = v; return 0; }
+    set_error("tile size %d must be 256 x {4,7,8,12,16}", v);
+    return 1;
+}
+
+// Finish a handle whose CSR arrays are in HBM (d_row_ptr/d_col/d_val set,
+// `csr_val_is_f64` tells the element type of d_val).
+static int finish_from_device_csr(spmv_hip_matrix *m, int64_t p0, int64_t p1, bool csr_val_is_f64, hipStream_t st)
+{
+    switch (m->format) {
+    case SPMV_HIP_CSR_SCALAR: m->lanes_per_row = 1; return 0;
+    case SPMV_HIP_CSR_VECTOR: {
+        int g = p0 ? (int)p0 : choose_lanes_per_row(m->rows, m->stored);
+        if (g < 2 || g > 64 || (g & (g - 1))) { set_error("lanes_per_row %d must be a power of two in 2..64", g); return 1; }
+        m->lanes_per_row = g;
+        return 0;
+    }
+    case SPMV_HIP_CSR_MERGE:
+        if (normalize_tile_param(p0, 7 * kBlock, &m->items_per_tile)) return 1;
+        return build_merge_tiles(m, st);
+    case SPMV_HIP_CSR_BAL:
+        if (normalize_tile_param(p0, 7 * kBlock, &m->items_per_tile)) return 1;
+        return build_bal_tiles(m, st);
+    case SPMV_HIP_SELL:
+    case SPMV_HIP_SELLP:
+    case SPMV_HIP_ELL: {
+        const bool sell = m->format == SPMV_HIP_SELL;
+        m->slice_height = p0 ? (int)p0 : kDefaultC;
+        m->sigma = sell ? (p1 ? p1 : kDefaultSigma) : 0;
+        if (sell && m->sigma < 1) { set_error("sigma must be positive"); return 1; }
+        const int *rp = m->d_row_ptr, *cj = m->d_col;
+        const void *va = m->d_val;
+        int64_t csr_bytes = m->owns_csr ? m->device_bytes : 0;
+        int rc = build_sliced(m, rp, cj, va, csr_val_is_f64, sell, st);
+        // the sliced layout replaces the CSR arrays
+        release_csr(m);
+        m->device_bytes -= csr_bytes;
+        return rc;
+    }
+    default: set_error("unknown format %d", m->format); return 1;
+    }
+}
+
+static spmv_hip_matrix *create_from_host_csr(int format, int rows, int columns, int64_t nnz, const std::vector<int> &rp,
+                                             const std::vector<int> &cj, const std::vector<double> &va, int dtype,
+                                             int64_t p0, int64_t p1)
+{
+    if (check_columns(columns, cj)) return nullptr;
+    spmv_hip_matrix *m = new_handle(format, dtype, rows, columns, nnz);
+    if (!m) return nullptr;
+    const bool sliced = format == SPMV_HIP_SELL || format == SPMV_HIP_SELLP || format == SPMV_HIP_ELL;
+    if (upload_csr(m, rp, cj, va, /*keep_f64_values=*/sliced) || finish_from_device_csr(m, p0, p1, sliced || dtype == SPMV_HIP_F64, nullptr)) {
+        spmv_hip_free(m);
+        return nullptr;
+    }
+    return m;
+}
+
+static spmv_hip_matrix *create_from_coo(int format, int rows, int columns, int nnz, int alignment, struct mtx *coo,
+                                        int dtype, int64_t p0, int64_t p1)
+{
+    clear_error();
+    if (check_dims(rows, columns, nnz, dtype)) return nullptr;
+    if (nnz > 0 && !coo) { set_error("coo is NULL"); return nullptr; }
+    sort_coo_in_place(nnz, coo);
+    std::vector<int> rp, cj;
+    std::vector<double> va;
+    if (coo_to_csr(rows, nnz, alignment, coo, rp, cj, va)) return nullptr;
+    return create_from_host_csr(format, rows, columns, nnz, rp, cj, va, dtype, p0, p1);
+}
+
+static spmv_hip_matrix *create_from_csr_arrays(int format, int rows, int columns, int nnz, const int *row_ptr,
+                                               const int *col, const double *A, int dtype, int64_t p0, int64_t p1)
+{
+    clear_error();
+    if (check_dims(rows, columns, nnz, dtype)) return nullptr;
+    if (!row_ptr || (nnz > 0 && (!col || !A))) { set_error("NULL CSR array"); return nullptr; }
+    if (row_ptr[0] != 0 || row_ptr[rows] != nnz) { set_error("row_ptr[0] must be 0 and row_ptr[rows] must equal nnz"); return nullptr; }
+    for (int r = 0; r < rows; r++)
+        if (row_ptr[r + 1] < row_ptr[r]) { set_error("row_ptr decreases at row %d", r); return nullptr; }
+    std::vector<int> rp(row_ptr, row_ptr + rows + 1), cj(col, col + nnz);
+    std::vector<double> va(A, A + nnz);
+    return create_from_host_csr(format, rows, columns, nnz, rp, cj, va, dtype, p0, p1);
+}
+
+static int ensure_vectors(spmv_hip_matrix *m)
+{
+    const size_t es = dtype_size(m->dtype);
+    if (!m->d_x && dev_alloc(m, (char **)&m->d_x, (size_t)std::max(m->columns, 1) * es)) return 1;
+    if (!m->d_y && dev_alloc(m, (char **)&m->d_y, (size_t)std::max(m->rows, 1) * es)) return 1;
+    if (!m->d_norm && dev_alloc(m, &m->d_norm, 1)) return 1;
+    return 0;
+}
+
+static int upload_vector(const spmv_hip_matrix *m, void *d, const double *h, int n)
+{
+    if (n == 0) return 0;
+    if (m->dtype == SPMV_HIP_F64) {
+        SPMV_HIP_TRY(hipMemcpy(d, h, sizeof(double) * (size_t)n, hipMemcpyHostToDevice), return 1);
+    } else {
+        std::vector<float> f(h, h + n);
+        SPMV_HIP_TRY(hipMemcpy(d, f.data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice), return 1);
+    }
+    return 0;
+}
+
+static int download_vector(const spmv_hip_matrix *m, const void *d, double *h, int n)
+{
+    if (n == 0) return 0;
+    if (m->dtype == SPMV_HIP_F64) {
+        SPMV_HIP_TRY(hipMemcpy(h, d, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost), return 1);
+    } else {
+        std::vector<float> f((size_t)n);
+        SPMV_HIP_TRY(hipMemcpy(f.data(), d, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost), return 1);
+        for (int i = 0; i < n; i++) h[i] = (double)f[(size_t)i];
+    }
+    return 0;
+}
+
+} // namespace spmv
+
+using namespace spmv;
+
+extern "C" {
+
+int spmv_hip_init(int device)
+{
+    clear_error();
+    SPMV_HIP_TRY(hipSetDevice(device), return 1);
+    return 0;
+}
+
+const char *spmv_hip_last_error(void) { return g_error; }
+
+spmv_hip_matrix *spmv_hip_create_csr(int rows, int columns, int nnz, int alignment, struct mtx *coo, int dtype,
+                                     int kernel, int lanes_per_row)
+{
+    if (kernel != SPMV_HIP_CSR_SCALAR && kernel != SPMV_HIP_CSR_VECTOR) {
+        set_error("create_csr: kernel must be SPMV_HIP_CSR_SCALAR or SPMV_HIP_CSR_VECTOR");
+        return nullptr;
+    }
+    return create_from_coo(kernel, rows, columns, nnz, alignment, coo, dtype, lanes_per_row, 0);
+}
+
+spmv_hip_matrix *spmv_hip_create_csr_merge(int rows, int columns, int nnz, struct mtx *coo, int dtype, int items_per_tile)
+{
+    return create_from_coo(SPMV_HIP_CSR_MERGE, rows, columns, nnz, 1, coo, dtype, items_per_tile, 0);
+}
+
+spmv_hip_matrix *spmv_hip_create_csr_bal(int rows, int columns, int nnz, struct mtx *coo, int dtype, int nnz_per_tile)
+{
+    return create_from_coo(SPMV_HIP_CSR_BAL, rows, columns, nnz, 1, coo, dtype, nnz_per_tile, 0);
+}
+
+spmv_hip_matrix *spmv_hip_create_ell(int rows, int columns, int nnz, struct mtx *coo, int dtype, int slice_height)
+{
+    return create_from_coo(SPMV_HIP_ELL, rows, columns, nnz, 1, coo, dtype, slice_height, 0);
+}
+
+spmv_hip_matrix *spmv_hip_create_sellp(int rows, int columns, int nnz, const int *row_ptr, const int *col,
+                                       const double *A, int dtype, int slice_height)
+{
+    return create_from_csr_arrays(SPMV_HIP_SELLP, rows, columns, nnz, row_ptr, col, A, dtype, slice_height, 0);
+}
+
+spmv_hip_matrix *spmv_hip_create_sell(int rows, int columns, int nnz, const int *row_ptr, const int *col,
+                                      const double *A, int dtype, int C, int64_t sigma)
+{
+    return create_from_csr_arrays(SPMV_HIP_SELL, rows, columns, nnz, row_ptr, col, A, dtype, C, sigma);
+}
+
+spmv_hip_matrix *spmv_hip_create_from_device_csr(int format, int rows, int columns, int64_t nnz, const int *d_row_ptr,
+                                                 const int *d_col, const void *d_val, int dtype, int64_t p0, int64_t p1,
+                                                 void *stream)
+{
+    clear_error();
+    if (check_dims(rows, columns, nnz, dtype)) return nullptr;
+    if (nnz > 0x7fffffffLL) { set_error("nnz %lld exceeds the 32-bit row pointers of CSR", (long long)nnz); return nullptr; }
+    if (!d_row_ptr || (nnz > 0 && (!d_col || !d_val))) { set_error("NULL device CSR array"); return nullptr; }
+    spmv_hip_matrix *m = new_handle(format, dtype, rows, columns, nnz);
+    if (!m) return nullptr;
+    m->owns_csr = false;
+    m->stored = nnz;
+    m->d_row_ptr = const_cast<int *>(d_row_ptr);
+    m->d_col = const_cast<int *>(d_col);
+    m->d_val = const_cast<void *>(d_val);
+    if (finish_from_device_csr(m, p0, p1, dtype == SPMV_HIP_F64, (hipStream_t)stream)) {
+        spmv_hip_free(m);
+        return nullptr;
+    }
+    return m;
+}
+
+int spmv_hip_mult_dev(spmv_hip_matrix *m, const void *d_x, void *d_y, void *stream)
+{
+    if (!m) { set_error("NULL handle"); return 1; }
+    return launch_mult(m, d_x, d_y, (hipStream_t)stream);
+}
+
+int spmv_hip_mult(spmv_hip_matrix *m, const double *x, double *y)
+{
+    clear_error();
+    if (!m || !x || !y) { set_error("NULL argument"); return 1; }
+    if (ensure_vectors(m)) return 1;
+    if (upload_vector(m, m->d_x, x, m->columns)) return 1;
+    if (launch_mult(m, m->d_x, m->d_y, nullptr)) return 1;
+    SPMV_HIP_TRY(hipDeviceSynchronize(), return 1);
+    return download_vector(m, m->d_y, y, m->rows);
+}
+
+int spmv_hip_free(spmv_hip_matrix *m)
+{
+    if (!m) return 0;
+    release_csr(m);
+    void *ptrs[] = {m->d_tile_coord, m->d_row_carry, m->d_val_carry, m->d_nzr_id, m->d_nzr_end, m->d_slice_ptr,
+                    m->d_row_order, m->d_scol, m->d_sval, m->d_x, m->d_y, m->d_norm};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete m;
+    return 0;
+}
+
+int spmv_hip_bench(spmv_hip_matrix *m, int min_iters, double min_seconds, double *x, int *iters, double *seconds)
+{
+    clear_error();
+    if (!m || !x || !iters || !seconds) { set_error("NULL argument"); return 1; }
+    if (m->rows != m->columns) { set_error("bench: matrix is not square"); return 1; }
+    if (ensure_vectors(m)) return 1;
+    if (upload_vector(m, m->d_x, x, m->columns)) return 1;
+    hipEvent_t e0, e1;
+    SPMV_HIP_TRY(hipEventCreate(&e0), return 1);
+    SPMV_HIP_TRY(hipEventCreate(&e1), return 1);
+    int rc = 1, it = 0;
+    double total_ms = 0.0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        it++;
+        SPMV_HIP_TRY(hipEventRecord(e0, nullptr), break);
+        if (launch_mult(m, m->d_x, m->d_y, nullptr)) break;
+        SPMV_HIP_TRY(hipEventRecord(e1, nullptr), break);
+        if (launch_norm2(m->rows, m->d_y, m->dtype, m->d_norm, nullptr)) break;
+        if (launch_scale(m->rows, m->d_y, m->d_x, m->dtype, m->d_norm, nullptr)) break;
+        SPMV_HIP_TRY(hipEventSynchronize(e1), break);
+        float ms = 0;
+        SPMV_HIP_TRY(hipEventElapsedTime(&ms, e0, e1), break);
+        total_ms += ms;
+        double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (wall > min_seconds && it >= min_iters) { rc = 0; break; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    SPMV_HIP_TRY(hipDeviceSynchronize(), return 1);
+    *iters = it;
+    *seconds = total_ms * 1e-3;
+    return download_vector(m, m->d_x, x, m->columns);
+}
+
+int spmv_hip_norm2_dev(int n, const void *d_x, int dtype, double *d_out, void *stream)
+{
+    return launch_norm2(n, d_x, dtype, d_out, (hipStream_t)stream);
+}
+
+int spmv_hip_scale_dev(int n, const void *d_y, void *d_x, int dtype, const double *d_norm, void *stream)
+{
+    return launch_scale(n, d_y, d_x, dtype, d_norm, (hipStream_t)stream);
+}
+
+int spmv_hip_get_info(const spmv_hip_matrix *m, spmv_hip_info *info)
+{
+    if (!m || !info) { set_error("NULL argument"); return 1; }
+    memset(info, 0, sizeof *info);
+    info->format = m->format; info->dtype = m->dtype;
+    info->rows = m->rows; info->columns = m->columns;
+    info->nnz = m->nnz; info->stored = m->stored;
+    info->slice_height = m->slice_height; info->sigma = m->sigma; info->nslices = m->nslices;
+    info->lanes_per_row = m->lanes_per_row;
+    info->ntiles = m->ntiles; info->items_per_tile = m->items_per_tile;
+    info->device_bytes = m->device_bytes;
+    return 0;
+}
+
+int spmv_hip_download(const spmv_hip_matrix *m, int which, void *host, size_t bytes)
+{
+    clear_error();
+    if (!m || !host) { set_error("NULL argument"); return 1; }
+    const void *src = nullptr;
+    size_t need = 0;
+    const bool sliced = m->d_slice_ptr != nullptr;
+    switch (which) {
+    case SPMV_HIP_ARR_ROW_PTR: src = m->d_row_ptr; need = sizeof(int) * ((size_t)m->rows + 1); break;
+    case SPMV_HIP_ARR_COL: src = sliced ? m->d_scol : m->d_col; need = sizeof(int) * (size_t)m->stored; break;
+    case SPMV_HIP_ARR_VAL: src = sliced ? m->d_sval : m->d_val; need = dtype_size(m->dtype) * (size_t)m->stored; break;
+    case SPMV_HIP_ARR_SLICE_PTR: src = m->d_slice_ptr; need = sizeof(int64_t) * ((size_t)m->nslices + 1); break;
+    case SPMV_HIP_ARR_ROW_ORDER: src = m->d_row_order; need = sizeof(int) * (size_t)m->rows; break;
+    case SPMV_HIP_ARR_TILE_COORD: src = m->d_tile_coord; need = sizeof(int) * 2 * ((size_t)m->ntiles + 1); break;
+    default: set_error("unknown array id %d", which); return 1;
+    }
+    if (!src) { set_error("array %d is not part of format %d", which, m->format); return 1; }
+    if (bytes != need) { set_error("array %d holds %zu bytes, caller passed %zu", which, need, bytes); return 1; }
+    if (need == 0) return 0;
+    SPMV_HIP_TRY(hipMemcpy(host, src, need, hipMemcpyDeviceToHost), return 1);
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,242 @@
+// Format converters: build the HBM-resident layouts of every format from a
+// CSR that already sits in HBM.  The heavy passes (sigma-window sort, slice
+// fill, merge-path partition) run on the device; prefix sums over per-slice /
+// per-row metadata run on the host at create time.
+
+#include "internal.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace spmv {
+
+static inline unsigned cdiv64(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+// mean row length -> lanes per row for the vector CSR kernel (power of two, 2..64)
+int choose_lanes_per_row(int rows, int64_t stored)
+{
+    double mean = rows > 0 ? (double)stored / rows : 0.0;
+    int g = 2;
+    while (g < 64 && g < mean) g *= 2;
+    return g;
+}
+
+// ------------------------------------------------------------- merge path ----
+
+// One thread per tile boundary: the 2-D diagonal search of the reference
+// (csr_merge.c:62-85) on the global row-end list.
+__global__ void merge_partition_kernel(int ntiles, int items_per_tile, int n, int nz,
+                                       const int *__restrict__ row_end, int *__restrict__ tile_coord)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > ntiles) return;
+    int64_t d64 = (int64_t)t * items_per_tile;
+    int64_t items = (int64_t)n + nz;
+    int d = (int)(d64 < items ? d64 : items);
+    int lo = d > nz ? d - nz : 0;
+    int hi = d < n ? d : n;
+    while (lo < hi) {
+        int mid = (int)(((int64_t)lo + hi) >> 1);
+        if (row_end[mid] <= d - mid - 1) lo = mid + 1; else hi = mid;
+    }
+    tile_coord[2 * t] = lo;
+    tile_coord[2 * t + 1] = d - lo;
+}
+
+int build_merge_tiles(spmv_hip_matrix *m, hipStream_t st)
+{
+    int64_t items = (int64_t)m->rows + m->stored;
+    if (items >= 0x7fffffffLL) { set_error("csr_merge: rows + nnz = %lld does not fit 32-bit path coordinates", (long long)items); return 1; }
+    m->ntiles = (int)((items + m->items_per_tile - 1) / m->items_per_tile);
+    if (dev_alloc(m, &m->d_tile_coord, 2 * ((size_t)m->ntiles + 1))) return 1;
+    if (dev_alloc(m, &m->d_row_carry, (size_t)m->ntiles)) return 1;
+    if (dev_alloc(m, (char **)&m->d_val_carry, (size_t)m->ntiles * dtype_size(m->dtype))) return 1;
+    hipLaunchKernelGGL(merge_partition_kernel, dim3(cdiv64(m->ntiles + 1, 256)), dim3(256), 0, st, m->ntiles,
+                       m->items_per_tile, m->rows, (int)m->stored, m->d_row_ptr + 1, m->d_tile_coord);
+    SPMV_HIP_TRY(hipGetLastError(), return 1);
+    SPMV_HIP_TRY(hipStreamSynchronize(st), return 1);
+    return 0;
+}
+
+// ------------------------------------------------------------ balanced CSR ----
+
+// Equal-nnz tiles (reference csr_bal.c:83-85) over the list of non-empty rows
+// (the reference's per-chunk local CSR holds exactly those: csr_bal.c:45-59).
+// tile_coord[2t] = first non-empty row whose end lies beyond the tile start,
+// tile_coord[2t+1] = tile start in the non-zero array.
+int build_bal_tiles(spmv_hip_matrix *m, hipStream_t st)
+{
+    const int rows = m->rows;
+    const int64_t nnz = m->stored;
+    std::vector<int> rp((size_t)rows + 1);
+    SPMV_HIP_TRY(hipMemcpyAsync(rp.data(), m->d_row_ptr, sizeof(int) * ((size_t)rows + 1), hipMemcpyDeviceToHost, st), return 1);
+    SPMV_HIP_TRY(hipStreamSynchronize(st), return 1);
+    std::vector<int> id, end;
+    id.reserve(rows); end.reserve(rows);
+    for (int r = 0; r < rows; r++)
+        if (rp[r + 1] > rp[r]) { id.push_back(r); end.push_back(rp[r + 1]); }
+    m->nz_rows = (int)id.size();
+    m->has_empty_rows = m->nz_rows != rows;
+    const int ch = m->items_per_tile;
+    m->ntiles = (int)((nnz + ch - 1) / ch);
+    std::vector<int> coord(2 * ((size_t)m->ntiles + 1));
+    for (int t = 0; t <= m->ntiles; t++) {
+        int64_t b = std::min<int64_t>((int64_t)t * ch, nnz);
+        int a = (int)(std::upper_bound(end.begin(), end.end(), (int)b) - end.begin());
+        coord[2 * t] = a;
+        coord[2 * t + 1] = (int)b;
+    }
+    if (dev_alloc(m, &m->d_nzr_id, id.size())) return 1;
+    if (dev_alloc(m, &m->d_nzr_end, end.size())) return 1;
+    if (dev_alloc(m, &m->d_tile_coord, coord.size())) return 1;
+    if (dev_alloc(m, &m->d_row_carry, (size_t)m->ntiles)) return 1;
+    if (dev_alloc(m, (char **)&m->d_val_carry, (size_t)m->ntiles * dtype_size(m->dtype))) return 1;
+    if (!id.empty()) {
+        SPMV_HIP_TRY(hipMemcpyAsync(m->d_nzr_id, id.data(), sizeof(int) * id.size(), hipMemcpyHostToDevice, st), return 1);
+        SPMV_HIP_TRY(hipMemcpyAsync(m->d_nzr_end, end.data(), sizeof(int) * end.size(), hipMemcpyHostToDevice, st), return 1);
+    }
+    SPMV_HIP_TRY(hipMemcpyAsync(m->d_tile_coord, coord.data(), sizeof(int) * coord.size(), hipMemcpyHostToDevice, st), return 1);
+    SPMV_HIP_TRY(hipStreamSynchronize(st), return 1);
+    return 0;
+}
+
+// ---------------------------------------------------------- sliced formats ----
+
+// Stable descending sort of the row lengths inside one sigma window per
+// workgroup (reference radix_sort.c:103-122: LSD radix, larger digit first,
+// ties keep ascending row index).  Rank by counting in LDS: position of row i =
+// #{j : len_j > len_i} + #{j < i : len_j == len_i}.
+__global__ __launch_bounds__(1024) void sell_window_sort_kernel(int rows, int window,
+                                                                const int *__restrict__ row_ptr,
+                                                                int *__restrict__ row_order,
+                                                                int *__restrict__ sorted_len)
+{
+    extern __shared__ int lens[];
+    const int w0 = blockIdx.x * window;
+    const int n = min(window, rows - w0);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) lens[i] = row_ptr[w0 + i + 1] - row_ptr[w0 + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int li = lens[i];
+        int rank = 0;
+        for (int j = 0; j < n; j++) {
+            int lj = lens[j];
+            rank += (lj > li) | ((lj == li) & (j < i));
+        }
+        row_order[w0 + rank] = w0 + i;
+        sorted_len[w0 + rank] = li;
+    }
+}
+
+// Width of every slice: length of its first row when the rows were sorted
+// (reference sellcs_format.c:152-158), longest row otherwise (sellp.c:411-421,
+// ell.c:72-82).
+__global__ void slice_width_kernel(int rows, int height, int nslices, const int *__restrict__ row_ptr,
+                                   const int *__restrict__ sorted_len, int *__restrict__ width)
+{
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nslices) return;
+    int64_t r0 = (int64_t)s * height;
+    if (sorted_len) { width[s] = sorted_len[r0]; return; }
+    int w = 0;
+    for (int k = 0; k < height && r0 + k < rows; k++) w = max(w, row_ptr[r0 + k + 1] - row_ptr[r0 + k]);
+    width[s] = w;
+}
+
+// Column-major slice fill with (col 0, value 0) padding (reference
+// sellcs_format.c:164-187, sellp.c:433-453).  One thread per slice lane.
+template <typename Tin, typename Tout>
+__global__ __launch_bounds__(256) void slice_fill_kernel(int rows, int height, int64_t lanes,
+                                                         const int *__restrict__ row_ptr,
+                                                         const int *__restrict__ col, const Tin *__restrict__ val,
+                                                         const int *__restrict__ row_order,
+                                                         const int64_t *__restrict__ slice_ptr,
+                                                         int *__restrict__ scol, Tout *__restrict__ sval)
+{
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= lanes) return;
+    int s = (int)(r / height), k = (int)(r - (int64_t)s * height);
+    int64_t base = slice_ptr[s];
+    int width = (int)((slice_ptr[s + 1] - base) / height);
+    int beg = 0, len = 0;
+    if (r < rows) {
+        int src = row_order ? row_order[r] : (int)r;
+        beg = row_ptr[src];
+        len = row_ptr[src + 1] - beg;
+    }
+    for (int j = 0; j < width; j++) {
+        int64_t at = base + (int64_t)j * height + k;
+        bool live = j < len;
+        scol[at] = live ? col[beg + j] : 0;
+        sval[at] = live ? (Tout)val[beg + j] : (Tout)0;
+    }
+}
+
+int build_sliced(spmv_hip_matrix *m, const int *d_row_ptr, const int *d_col, const void *d_val,
+                 bool val_is_f64, bool sorted, hipStream_t st)
+{
+    const int rows = m->rows, H = m->slice_height;
+    if (H < 1 || H > kWave || (H & (H - 1))) { set_error("slice height %d must be a power of two <= 64", H); return 1; }
+    m->nslices = (rows + H - 1) / H;
+    int *d_sorted_len = nullptr, *d_width = nullptr;
+    int rc = 1;
+    std::vector<int> width((size_t)m->nslices);
+    std::vector<int64_t> sp((size_t)m->nslices + 1);
+    do {
+        if (sorted && rows > 0) {
+            int64_t window = std::min<int64_t>(m->sigma, rows);
+            if (m->sigma % H != 0 && m->sigma < rows) {
+                set_error("sell: sigma %lld must be a multiple of C %d", (long long)m->sigma, H);
+                break;
+            }
+            if (window > kMaxSigma) { set_error("sell: sorting window %lld exceeds %lld rows", (long long)window, (long long)kMaxSigma); break; }
+            if (dev_alloc(m, &m->d_row_order, (size_t)rows)) break;
+            if (dev_alloc<int>(nullptr, &d_sorted_len, (size_t)rows)) break;
+            size_t lds = (size_t)window * sizeof(int);
+            SPMV_HIP_TRY(hipFuncSetAttribute((const void *)sell_window_sort_kernel,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), break);
+            hipLaunchKernelGGL(sell_window_sort_kernel, dim3(cdiv64(rows, window)), dim3(1024), lds, st, rows,
+                               (int)window, d_row_ptr, m->d_row_order, d_sorted_len);
+            SPMV_HIP_TRY(hipGetLastError(), break);
+        }
+        if (m->nslices > 0) {
+            if (dev_alloc<int>(nullptr, &d_width, (size_t)m->nslices)) break;
+            hipLaunchKernelGGL(slice_width_kernel, dim3(cdiv64(m->nslices, 256)), dim3(256), 0, st, rows, H,
+                               m->nslices, d_row_ptr, d_sorted_len, d_width);
+            SPMV_HIP_TRY(hipGetLastError(), break);
+            SPMV_HIP_TRY(hipMemcpyAsync(width.data(), d_width, sizeof(int) * width.size(), hipMemcpyDeviceToHost, st), break);
+        }
+        SPMV_HIP_TRY(hipStreamSynchronize(st), break);
+        int64_t total = 0;
+        for (int s = 0; s < m->nslices; s++) { sp[s] = total; total += (int64_t)width[s] * H; }
+        sp[m->nslices] = total;
+        m->stored = total;
+        if (dev_alloc(m, &m->d_slice_ptr, sp.size())) break;
+        if (dev_alloc(m, &m->d_scol, (size_t)total)) break;
+        if (dev_alloc(m, (char **)&m->d_sval, (size_t)total * dtype_size(m->dtype))) break;
+        SPMV_HIP_TRY(hipMemcpyAsync(m->d_slice_ptr, sp.data(), sizeof(int64_t) * sp.size(), hipMemcpyHostToDevice, st), break);
+        if (total > 0) {
+            int64_t lanes = (int64_t)m->nslices * H;
+            dim3 grid(cdiv64(lanes, 256)), block(256);
+            const bool f32 = m->dtype == SPMV_HIP_F32;
+            if (val_is_f64 && !f32)
+                hipLaunchKernelGGL((slice_fill_kernel<double, double>), grid, block, 0, st, rows, H, lanes, d_row_ptr, d_col,
+                                   (const double *)d_val, m->d_row_order, m->d_slice_ptr, m->d_scol, (double *)m->d_sval);
+            else if (val_is_f64 && f32)
+                hipLaunchKernelGGL((slice_fill_kernel<double, float>), grid, block, 0, st, rows, H, lanes, d_row_ptr, d_col,
+                                   (const double *)d_val, m->d_row_order, m->d_slice_ptr, m->d_scol, (float *)m->d_sval);
+            else if (!val_is_f64 && f32)
+                hipLaunchKernelGGL((slice_fill_kernel<float, float>), grid, block, 0, st, rows, H, lanes, d_row_ptr, d_col,
+                                   (const float *)d_val, m->d_row_order, m->d_slice_ptr, m->d_scol, (float *)m->d_sval);
+            else { set_error("sliced: float CSR values cannot build a double matrix"); break; }
+            SPMV_HIP_TRY(hipGetLastError(), break);
+        }
+        SPMV_HIP_TRY(hipStreamSynchronize(st), break);
+        rc = 0;
+    } while (0);
+    if (d_sorted_len) (void)hipFree(d_sorted_len);
+    if (d_width) (void)hipFree(d_width);
+    return rc;
+}
+
+} // namespace spmv

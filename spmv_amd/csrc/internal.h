@@ -1,0 +1,105 @@
+// Internal declarations shared by the translation units of libspmv_hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "spmv_hip.h"
+
+namespace spmv {
+
+constexpr int kWave = 64;            // gfx950 wavefront
+constexpr int kBlock = 256;          // threads per workgroup for every SpMV kernel
+constexpr int kDefaultSigma = 16384; // sell.c:4
+constexpr int kDefaultC = 64;        // sell.c:5 (max_vlen), = one wave64
+constexpr int64_t kMaxSigma = 32768; // one sorting window must fit in LDS
+
+void set_error(const char *fmt, ...);
+void clear_error();
+
+#define SPMV_HIP_TRY(expr, onfail)                                                        \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            spmv::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),        \
+                            __FILE__, __LINE__);                                          \
+            onfail;                                                                       \
+        }                                                                                 \
+    } while (0)
+
+inline size_t dtype_size(int dtype) { return dtype == SPMV_HIP_F32 ? 4 : 8; }
+
+} // namespace spmv
+
+// The opaque handle of the C ABI.
+struct spmv_hip_matrix {
+    int format = 0, dtype = 0, device = 0;
+    int rows = 0, columns = 0;
+    int64_t nnz = 0;      // true non-zeros
+    int64_t stored = 0;   // entries in HBM incl. padding
+
+    // CSR family.  owns_csr == false when the arrays were adopted from the caller.
+    bool owns_csr = true;
+    int *d_row_ptr = nullptr;
+    int *d_col = nullptr;
+    void *d_val = nullptr;
+    int lanes_per_row = 0;
+
+    // merge-path / balanced tiles
+    int ntiles = 0, items_per_tile = 0;
+    int *d_tile_coord = nullptr;   // 2*(ntiles+1) ints
+    int *d_row_carry = nullptr;    // ntiles
+    void *d_val_carry = nullptr;   // ntiles (dtype)
+    // balanced CSR: compacted non-empty rows
+    int nz_rows = 0;               // number of non-empty rows
+    int *d_nzr_id = nullptr;       // [nz_rows] original row index
+    int *d_nzr_end = nullptr;      // [nz_rows] row end offsets (row_ptr[row+1])
+    bool has_empty_rows = false;
+
+    // sliced formats (SELL-C-sigma, SELLP, ELL)
+    int slice_height = 0, nslices = 0;
+    int64_t sigma = 0;
+    int64_t *d_slice_ptr = nullptr; // nslices+1
+    int *d_row_order = nullptr;     // rows (SELL only)
+    int *d_scol = nullptr;          // stored
+    void *d_sval = nullptr;         // stored (dtype)
+
+    // staging vectors for the host-pointer multiply and the bench loop
+    void *d_x = nullptr, *d_y = nullptr;
+    double *d_norm = nullptr;
+
+    int64_t device_bytes = 0;
+};
+
+namespace spmv {
+
+// kernels.hip -- asynchronous launches on `stream`
+int launch_mult(const spmv_hip_matrix *m, const void *d_x, void *d_y, hipStream_t stream);
+int launch_norm2(int n, const void *d_x, int dtype, double *d_out, hipStream_t stream);
+int launch_scale(int n, const void *d_y, void *d_x, int dtype, const double *d_norm, hipStream_t stream);
+
+// convert.hip -- build device layouts from a CSR resident in HBM.
+// `val_is_f64`: element type of d_val (host creators upload doubles; the device
+// creator hands over dtype elements).
+int choose_lanes_per_row(int rows, int64_t stored);
+int build_merge_tiles(spmv_hip_matrix *m, hipStream_t stream);
+int build_bal_tiles(spmv_hip_matrix *m, hipStream_t stream);
+int build_sliced(spmv_hip_matrix *m, const int *d_row_ptr, const int *d_col, const void *d_val,
+                 bool val_is_f64, bool sorted, hipStream_t stream);
+int convert_f64_to_f32(int64_t n, const double *d_in, float *d_out, hipStream_t stream);
+
+template <typename T> int dev_alloc(spmv_hip_matrix *m, T **p, size_t count)
+{
+    *p = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc((void **)p, count * sizeof(T));
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+        return 1;
+    }
+    if (m) m->device_bytes += (int64_t)(count * sizeof(T));
+    return 0;
+}
+
+} // namespace spmv

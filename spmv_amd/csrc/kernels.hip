@@ -1,0 +1,499 @@
+// SpMV kernels for gfx950 (MI355X): wave64, 256-thread workgroups, HBM-bound.
+//
+// Every kernel walks the matrix in storage order so that consecutive workgroup
+// ids stream consecutive HBM addresses; the workgroup id is first remapped so
+// that each XCD (workgroups are dealt round-robin over the 8 XCDs) owns one
+// contiguous eighth of the matrix and its private L2 keeps that eighth's window
+// of x instead of all eight L2s caching the same window.
+//
+// Summation order per kernel (what the parity tolerance has to cover):
+//   csr_scalar, sliced (lane per row): ascending column position, one fma per
+//     entry -- the order of mult_csr_base (reference csr.c:4-13); bit-identical
+//     to it.
+//   csr_vector: G interleaved partial sums per row + butterfly.
+//   tile (merge-path / balanced): product rounded, then per-thread runs,
+//     segmented scan over threads, tile carries added in tile order.
+
+#include "internal.h"
+
+#include <algorithm>
+
+namespace spmv {
+
+// ------------------------------------------------------------------ helpers --
+
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// Workgroups b, b+8, b+16, ... share an XCD.  Give XCD-group g the g-th
+// contiguous run of logical blocks.  Bijective for any grid size.
+__device__ __forceinline__ unsigned xcd_contiguous_block(unsigned bid, unsigned nblocks)
+{
+    unsigned q = nblocks >> 3, r = nblocks & 7u, g = bid & 7u, idx = bid >> 3;
+    unsigned base = g < r ? g * (q + 1) : r * (q + 1) + (g - r) * q;
+    return base + idx;
+}
+
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v)
+{
+    long long bits = __builtin_bit_cast(long long, v);
+    int lo = (int)(bits & 0xFFFFFFFFll), hi = (int)(bits >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    bits = ((long long)hi << 32) | (unsigned int)lo;
+    return __builtin_bit_cast(double, bits);
+}
+
+// Sum over aligned groups of G lanes; every lane of the group ends with the
+// total.  DPP inside a 16-lane row (quad_perm xor1 / xor2, row_half_mirror,
+// row_mirror), ds_bpermute shuffles across rows.
+template <int G, typename T> __device__ __forceinline__ T group_sum(T v)
+{
+    if (G >= 2) v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    if (G >= 4) v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    if (G >= 8) v += dpp_mov<0x141>(v);  // row_half_mirror
+    if (G >= 16) v += dpp_mov<0x140>(v); // row_mirror
+    if (G >= 32) v += __shfl_xor(v, 16, 64);
+    if (G >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// ------------------------------------------------------------- CSR, 1 lane --
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void csr_scalar_kernel(int rows, const int *__restrict__ row_ptr,
+                                                            const int *__restrict__ col,
+                                                            const T *__restrict__ val,
+                                                            const T *__restrict__ x, T *__restrict__ y)
+{
+    unsigned b = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    int row = (int)(b * kBlock + threadIdx.x);
+    if (row >= rows) return;
+    int beg = row_ptr[row], end = row_ptr[row + 1];
+    T s = 0;
+    for (int l = beg; l < end; l++) s = fma_t(x[col[l]], val[l], s);
+    y[row] = s;
+}
+
+// --------------------------------------------------------- CSR, G lanes/row --
+
+template <typename T, int G>
+__global__ __launch_bounds__(kBlock) void csr_vector_kernel(int rows, const int *__restrict__ row_ptr,
+                                                            const int *__restrict__ col,
+                                                            const T *__restrict__ val,
+                                                            const T *__restrict__ x, T *__restrict__ y)
+{
+    constexpr int kRowsPerBlock = kBlock / G;
+    unsigned b = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    int row = (int)(b * kRowsPerBlock + threadIdx.x / G);
+    int lane = threadIdx.x % G;
+    T s = 0;
+    if (row < rows) {
+        int beg = row_ptr[row], end = row_ptr[row + 1];
+        for (int l = beg + lane; l < end; l += G) s = fma_t(x[col[l]], val[l], s);
+    }
+    s = group_sum<G>(s);
+    if (lane == 0 && row < rows) y[row] = s;
+}
+
+// ------------------------------------------- sliced formats, slice height 64 --
+// One wave per slice, lane = row of the slice.  Slice storage is column-major
+// (reference sellcs_format.c:174-187, sellp.c:440-452): entry j of lane k sits
+// at slice_ptr[s] + j*64 + k, so every wave load is one contiguous 512-byte
+// (values, fp64) or 256-byte (columns) run.  U independent columns are loaded
+// before their gathers so that U*768 bytes per wave are in flight.
+
+template <typename T, bool PERM, int U>
+__global__ __launch_bounds__(kBlock) void sliced64_kernel(int rows, int nslices,
+                                                          const int64_t *__restrict__ slice_ptr,
+                                                          const int *__restrict__ row_order,
+                                                          const int *__restrict__ scol,
+                                                          const T *__restrict__ sval,
+                                                          const T *__restrict__ x, T *__restrict__ y)
+{
+    unsigned b = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    int s = __builtin_amdgcn_readfirstlane((int)(b * (kBlock / kWave) + threadIdx.x / kWave));
+    if (s >= nslices) return;
+    int lane = threadIdx.x & (kWave - 1);
+    int64_t base = slice_ptr[s];
+    int width = (int)((slice_ptr[s + 1] - base) >> 6);
+    const T *v = sval + base + lane;
+    const int *c = scol + base + lane;
+    T acc = 0;
+    int j = 0;
+    for (; j + U <= width; j += U) {
+        int cc[U];
+        T vv[U], xx[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) cc[u] = c[(int64_t)(j + u) * kWave];
+#pragma unroll
+        for (int u = 0; u < U; u++) vv[u] = v[(int64_t)(j + u) * kWave];
+#pragma unroll
+        for (int u = 0; u < U; u++) xx[u] = x[cc[u]];
+#pragma unroll
+        for (int u = 0; u < U; u++) acc = fma_t(xx[u], vv[u], acc);
+    }
+    for (; j < width; j++) acc = fma_t(x[c[(int64_t)j * kWave]], v[(int64_t)j * kWave], acc);
+    int r = s * kWave + lane;
+    if (r < rows) y[PERM ? row_order[r] : r] = acc;
+}
+
+// ------------------------------------- sliced formats, any slice height <= 64 --
+// Lane per row; used for the reference's CPU-shaped slice heights (2, 4, 8).
+
+template <typename T, bool PERM>
+__global__ __launch_bounds__(kBlock) void sliced_any_kernel(int rows, int height,
+                                                            const int64_t *__restrict__ slice_ptr,
+                                                            const int *__restrict__ row_order,
+                                                            const int *__restrict__ scol,
+                                                            const T *__restrict__ sval,
+                                                            const T *__restrict__ x, T *__restrict__ y)
+{
+    unsigned b = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    int r = (int)(b * kBlock + threadIdx.x);
+    if (r >= rows) return;
+    int s = r / height, k = r - s * height;
+    int64_t base = slice_ptr[s];
+    int width = (int)((slice_ptr[s + 1] - base) / height);
+    T acc = 0;
+    for (int j = 0; j < width; j++) {
+        int64_t at = base + (int64_t)j * height + k;
+        acc = fma_t(x[scol[at]], sval[at], acc);
+    }
+    y[PERM ? row_order[r] : r] = acc;
+}
+
+// ------------------------------------------------ merge-path / balanced tiles --
+// One workgroup per tile.  A tile is the path segment between two precomputed
+// coordinates (a = position in the row-end list, b = position in the non-zero
+// list): tile_coord[2t..2t+1] -> tile_coord[2t+2..2t+3].
+//   merge-path CSR: row-end list = row_ptr+1, tiles are equal shares of the
+//     rows+nnz merge path (reference csr_merge.c:18-30).
+//   balanced CSR:   row-end list = ends of the non-empty rows, tiles are equal
+//     shares of the non-zeros (reference csr_bal.c:83-85); row_index maps a
+//     list position back to its row.
+// Phase 1 stages the tile's row ends and its products val*x[col] in LDS with
+// fully coalesced loads.  Phase 2 gives every thread an equal share of the
+// tile's path (2-D diagonal search in LDS, reference csr_merge.c:62-85) which
+// it consumes serially (csr_merge.c:32-46).  A row finished by a thread that
+// did not start it needs the partial sums of the threads before it: segmented
+// scan over the threads' trailing partial sums.  The tile's own trailing
+// partial goes to (row_carry, val_carry) and is added by tile_fixup_kernel in
+// tile order (csr_merge.c:48-58, csr_bal.c:33-37).
+
+template <typename T> struct SegPair { int flag; T value; };
+
+template <typename T>
+__device__ __forceinline__ SegPair<T> seg_combine(SegPair<T> left, SegPair<T> right)
+{
+    SegPair<T> r;
+    r.flag = left.flag | right.flag;
+    r.value = right.flag ? right.value : left.value + right.value;
+    return r;
+}
+
+template <typename T, int IPT>
+__global__ __launch_bounds__(kBlock) void tile_kernel(int list_len, const int *__restrict__ row_end_list,
+                                                      const int *__restrict__ row_index,
+                                                      const int *__restrict__ tile_coord,
+                                                      const int *__restrict__ col,
+                                                      const T *__restrict__ val,
+                                                      const T *__restrict__ x, T *__restrict__ y,
+                                                      int *__restrict__ row_carry, T *__restrict__ val_carry)
+{
+    constexpr int kCap = kBlock * IPT;       // most non-zeros (and most rows) of a tile
+    __shared__ T prod[kCap];
+    __shared__ int rend[kCap];
+    __shared__ int wave_flag[kBlock / kWave];
+    __shared__ T wave_val[kBlock / kWave];
+
+    const int t = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int tid = threadIdx.x;
+    const int a0 = tile_coord[2 * t], b0 = tile_coord[2 * t + 1];
+    const int a1 = tile_coord[2 * t + 2], b1 = tile_coord[2 * t + 3];
+    const int nr = a1 - a0, nz = b1 - b0, total = nr + nz;
+
+    // phase 1: coalesced staging
+#pragma unroll
+    for (int i = 0; i < IPT; i++) {
+        int k = tid + i * kBlock;
+        if (k < nz) prod[k] = val[b0 + k] * x[col[b0 + k]];
+    }
+    for (int k = tid; k < nr; k += kBlock) rend[k] = row_end_list[a0 + k] - b0;
+    __syncthreads();
+
+    // phase 2: this thread's share of the tile's path
+    const int per_thread = (total + kBlock - 1) / kBlock;
+    int d = min(tid * per_thread, total);
+    const int d_end = min(d + per_thread, total);
+    int lo = max(d - nz, 0), hi = min(d, nr);
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (rend[mid] <= d - mid - 1) lo = mid + 1; else hi = mid;
+    }
+    int a = lo, b = d - lo;
+
+    T run = 0, first_val = 0;
+    int first_row = -1;
+    for (; d < d_end; d++) {
+        int re = a < nr ? rend[a] : 0x7fffffff;
+        if (b < re) {
+            run += prod[b];
+            b++;
+        } else {
+            if (first_row < 0) { first_row = a; first_val = run; }
+            else y[row_index ? row_index[a0 + a] : a0 + a] = run;
+            run = 0;
+            a++;
+        }
+    }
+
+    // segmented inclusive scan of (finished a row?, trailing partial) over the workgroup
+    SegPair<T> p{first_row >= 0 ? 1 : 0, run};
+    const int lane = tid & (kWave - 1), wave = tid / kWave;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        SegPair<T> o;
+        o.flag = __shfl_up(p.flag, off, kWave);
+        o.value = __shfl_up(p.value, off, kWave);
+        if (lane >= off) p = seg_combine(o, p);
+    }
+    if (lane == kWave - 1) { wave_flag[wave] = p.flag; wave_val[wave] = p.value; }
+    // exclusive value inside the wave
+    T carry_in = __shfl_up(p.value, 1, kWave);
+    int carry_flag = __shfl_up(p.flag, 1, kWave);
+    if (lane == 0) { carry_in = 0; carry_flag = 0; }
+    __syncthreads();
+    SegPair<T> before{0, 0};                 // everything in the waves before this one
+    for (int w = 0; w < wave; w++) before = seg_combine(before, SegPair<T>{wave_flag[w], wave_val[w]});
+    if (!carry_flag) carry_in += before.value;
+
+    if (first_row >= 0) y[row_index ? row_index[a0 + first_row] : a0 + first_row] = first_val + carry_in;
+
+    if (tid == kBlock - 1) {
+        SegPair<T> all = seg_combine(before, p);
+        row_carry[t] = a1;
+        val_carry[t] = all.value;
+    }
+}
+
+// Adds the tiles' trailing partial sums to the rows they belong to, in tile
+// order (reference csr_merge.c:54-58).  One thread per run of equal row_carry.
+template <typename T>
+__global__ void tile_fixup_kernel(int ntiles, int list_len, const int *__restrict__ row_index,
+                                  const int *__restrict__ row_carry, const T *__restrict__ val_carry,
+                                  T *__restrict__ y)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    int a = row_carry[t];
+    if (a >= list_len) return;
+    if (t > 0 && row_carry[t - 1] == a) return;
+    int row = row_index ? row_index[a] : a;
+    T acc = y[row];
+    for (int u = t; u < ntiles && row_carry[u] == a; u++) acc += val_carry[u];
+    y[row] = acc;
+}
+
+// -------------------------------------------------------------- vector ops --
+
+constexpr int kNormBlocks = 1024;
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sumsq_partial_kernel(int n, const T *__restrict__ x,
+                                                               double *__restrict__ partial)
+{
+    __shared__ double wsum[kBlock / kWave];
+    double s = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        double v = (double)x[i];
+        s = __builtin_fma(v, v, s);
+    }
+    s = group_sum<64>(s);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+__global__ __launch_bounds__(kBlock) void sumsq_final_kernel(int nparts, const double *__restrict__ partial,
+                                                             double *__restrict__ out)
+{
+    __shared__ double wsum[kBlock / kWave];
+    double s = 0;
+    for (int i = threadIdx.x; i < nparts; i += kBlock) s += partial[i];
+    s = group_sum<64>(s);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = sqrt((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void scale_kernel(int n, const T *__restrict__ y, T *__restrict__ x,
+                                                       const double *__restrict__ norm)
+{
+    const double nrm = norm[0];
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        x[i] = (T)((double)y[i] / nrm);
+}
+
+// --------------------------------------------------------------- launchers --
+
+static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+template <typename T> static int launch_csr_vector(const spmv_hip_matrix *m, const T *x, T *y, hipStream_t st)
+{
+    const int *rp = m->d_row_ptr, *cj = m->d_col;
+    const T *va = (const T *)m->d_val;
+    int rows = m->rows;
+#define SPMV_VEC_CASE(G)                                                                              \
+    case G:                                                                                           \
+        hipLaunchKernelGGL((csr_vector_kernel<T, G>), dim3(cdiv(rows, kBlock / G)), dim3(kBlock), 0,  \
+                           st, rows, rp, cj, va, x, y);                                               \
+        break;
+    switch (m->lanes_per_row) {
+        SPMV_VEC_CASE(2)
+        SPMV_VEC_CASE(4)
+        SPMV_VEC_CASE(8)
+        SPMV_VEC_CASE(16)
+        SPMV_VEC_CASE(32)
+        SPMV_VEC_CASE(64)
+    default:
+        set_error("csr_vector: lanes_per_row %d is not one of 2,4,8,16,32,64", m->lanes_per_row);
+        return 1;
+    }
+#undef SPMV_VEC_CASE
+    return 0;
+}
+
+template <typename T> static int launch_sliced(const spmv_hip_matrix *m, const T *x, T *y, hipStream_t st)
+{
+    const T *sv = (const T *)m->d_sval;
+    const bool perm = m->d_row_order != nullptr;
+    if (m->slice_height == kWave) {
+        dim3 grid(cdiv(m->nslices, kBlock / kWave));
+        constexpr int U = sizeof(T) == 8 ? 8 : 8;
+        if (perm)
+            hipLaunchKernelGGL((sliced64_kernel<T, true, U>), grid, dim3(kBlock), 0, st, m->rows, m->nslices,
+                               m->d_slice_ptr, m->d_row_order, m->d_scol, sv, x, y);
+        else
+            hipLaunchKernelGGL((sliced64_kernel<T, false, U>), grid, dim3(kBlock), 0, st, m->rows, m->nslices,
+                               m->d_slice_ptr, m->d_row_order, m->d_scol, sv, x, y);
+    } else {
+        dim3 grid(cdiv(m->rows, kBlock));
+        if (perm)
+            hipLaunchKernelGGL((sliced_any_kernel<T, true>), grid, dim3(kBlock), 0, st, m->rows, m->slice_height,
+                               m->d_slice_ptr, m->d_row_order, m->d_scol, sv, x, y);
+        else
+            hipLaunchKernelGGL((sliced_any_kernel<T, false>), grid, dim3(kBlock), 0, st, m->rows, m->slice_height,
+                               m->d_slice_ptr, m->d_row_order, m->d_scol, sv, x, y);
+    }
+    return 0;
+}
+
+template <typename T> static int launch_tiles(const spmv_hip_matrix *m, const T *x, T *y, hipStream_t st)
+{
+    const bool bal = m->format == SPMV_HIP_CSR_BAL;
+    const int list_len = bal ? m->nz_rows : m->rows;
+    const int *list = bal ? m->d_nzr_end : m->d_row_ptr + 1;
+    const int *index = bal ? m->d_nzr_id : nullptr;
+    const T *va = (const T *)m->d_val;
+    T *vc = (T *)m->d_val_carry;
+    if (bal && m->has_empty_rows)
+        SPMV_HIP_TRY(hipMemsetAsync(y, 0, (size_t)m->rows * sizeof(T), st), return 1);
+    if (m->ntiles == 0) {
+        if (!bal && m->rows > 0) SPMV_HIP_TRY(hipMemsetAsync(y, 0, (size_t)m->rows * sizeof(T), st), return 1);
+        return 0;
+    }
+    // merge tiles hold items_per_tile path items; balanced tiles hold that many non-zeros
+    const int ipt = m->items_per_tile / kBlock;
+#define SPMV_TILE_CASE(I)                                                                            \
+    case I:                                                                                          \
+        hipLaunchKernelGGL((tile_kernel<T, I>), dim3(m->ntiles), dim3(kBlock), 0, st, list_len, list, \
+                           index, m->d_tile_coord, m->d_col, va, x, y, m->d_row_carry, vc);          \
+        break;
+    switch (ipt) {
+        SPMV_TILE_CASE(4)
+        SPMV_TILE_CASE(7)
+        SPMV_TILE_CASE(8)
+        SPMV_TILE_CASE(12)
+        SPMV_TILE_CASE(16)
+    default:
+        set_error("tile kernel: items_per_tile %d must be 256 x {4,7,8,12,16}", m->items_per_tile);
+        return 1;
+    }
+#undef SPMV_TILE_CASE
+    hipLaunchKernelGGL((tile_fixup_kernel<T>), dim3(cdiv(m->ntiles, kBlock)), dim3(kBlock), 0, st, m->ntiles,
+                       list_len, index, m->d_row_carry, vc, y);
+    return 0;
+}
+
+template <typename T> static int launch_mult_t(const spmv_hip_matrix *m, const T *x, T *y, hipStream_t st)
+{
+    int rc = 0;
+    if (m->rows == 0) return 0;
+    switch (m->format) {
+    case SPMV_HIP_CSR_SCALAR:
+        hipLaunchKernelGGL((csr_scalar_kernel<T>), dim3(cdiv(m->rows, kBlock)), dim3(kBlock), 0, st, m->rows,
+                           m->d_row_ptr, m->d_col, (const T *)m->d_val, x, y);
+        break;
+    case SPMV_HIP_CSR_VECTOR: rc = launch_csr_vector<T>(m, x, y, st); break;
+    case SPMV_HIP_CSR_MERGE:
+    case SPMV_HIP_CSR_BAL: rc = launch_tiles<T>(m, x, y, st); break;
+    case SPMV_HIP_SELL:
+    case SPMV_HIP_SELLP:
+    case SPMV_HIP_ELL: rc = launch_sliced<T>(m, x, y, st); break;
+    default: set_error("unknown format %d", m->format); return 1;
+    }
+    if (rc) return rc;
+    SPMV_HIP_TRY(hipGetLastError(), return 1);
+    return 0;
+}
+
+int launch_mult(const spmv_hip_matrix *m, const void *d_x, void *d_y, hipStream_t stream)
+{
+    if (m->dtype == SPMV_HIP_F32) return launch_mult_t<float>(m, (const float *)d_x, (float *)d_y, stream);
+    return launch_mult_t<double>(m, (const double *)d_x, (double *)d_y, stream);
+}
+
+// per-device scratch for the two-pass norm (kNormBlocks doubles), allocated on first use
+static double *norm_scratch()
+{
+    static double *scratch[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!scratch[dev] && hipMalloc((void **)&scratch[dev], kNormBlocks * sizeof(double)) != hipSuccess)
+        scratch[dev] = nullptr;
+    return scratch[dev];
+}
+
+int launch_norm2(int n, const void *d_x, int dtype, double *d_out, hipStream_t st)
+{
+    double *partial = norm_scratch();
+    if (!partial) { set_error("norm2: could not allocate scratch"); return 1; }
+    int blocks = (int)std::min<int64_t>(kNormBlocks, cdiv(std::max(n, 1), kBlock));
+    if (dtype == SPMV_HIP_F32)
+        hipLaunchKernelGGL((sumsq_partial_kernel<float>), dim3(blocks), dim3(kBlock), 0, st, n, (const float *)d_x, partial);
+    else
+        hipLaunchKernelGGL((sumsq_partial_kernel<double>), dim3(blocks), dim3(kBlock), 0, st, n, (const double *)d_x, partial);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(kBlock), 0, st, blocks, partial, d_out);
+    SPMV_HIP_TRY(hipGetLastError(), return 1);
+    return 0;
+}
+
+int launch_scale(int n, const void *d_y, void *d_x, int dtype, const double *d_norm, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    int blocks = (int)std::min<int64_t>(2048, cdiv(n, kBlock));
+    if (dtype == SPMV_HIP_F32)
+        hipLaunchKernelGGL((scale_kernel<float>), dim3(blocks), dim3(kBlock), 0, st, n, (const float *)d_y, (float *)d_x, d_norm);
+    else
+        hipLaunchKernelGGL((scale_kernel<double>), dim3(blocks), dim3(kBlock), 0, st, n, (const double *)d_y, (double *)d_x, d_norm);
+    SPMV_HIP_TRY(hipGetLastError(), return 1);
+    return 0;
+}
+
+} // namespace spmv

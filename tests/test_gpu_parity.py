@@ -1,0 +1,262 @@
+"""GPU parity: every format of libspmv_hip (through its C ABI) against the
+golden fixtures of the compiled reference and against the CPU oracle.
+
+Tolerances (fp64): lane-per-row kernels (csr_scalar, SELL, SELLP, ELL) keep
+mult_csr_base's summation order and must be BIT-EXACT with the reference's
+y_csr_base; kernels that reassociate (csr_vector, csr_merge, csr_bal) must meet
+rel-L2 <= 1e-13, far inside the reference's own bar of 1e-10
+(reference src/driver_spmv.c:313).  fp32 (no reference counterpart): rel-L2
+<= 2e-6 against the oracle's float restatement and <= 1e-5 against the fp64
+oracle.  Layouts (row_order, slice pointers, columns, values, tile
+coordinates) are compared bit for bit.
+"""
+import numpy as np
+import pytest
+
+import spmv_amd as S
+from spmv_amd.matrix import Matrix, coo_to_csr_host
+from tests import cases as CS
+from tests.util import bits_equal, coo_of, golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+NAMES = golden_names()
+TOL_REASSOC = 1e-13
+TOL_F32_VS_F32 = 2e-6
+TOL_F32_VS_F64 = 1e-5
+
+
+@pytest.fixture(scope="module", params=NAMES)
+def g(request):
+    d = load_golden(request.param)
+    d["name"] = request.param
+    return d
+
+
+def rel(orc, y, ref):
+    return orc.rel_l2(np.asarray(y, np.float64), np.asarray(ref, np.float64))
+
+
+def test_library_loaded_is_the_in_tree_hip_build():
+    assert S.LIB_PATH.endswith("spmv_amd/libspmv_hip.so")
+    S.lib()
+
+
+def test_create_sorts_coo_in_place_like_reference(g):
+    coo = coo_of(g, "in")
+    m = Matrix.csr(int(g["rows"]), int(g["cols"]), coo, 1, S.F64, S.CSR_SCALAR)
+    assert bits_equal(coo["i"], g["coo_sorted_i"]) and bits_equal(coo["j"], g["coo_sorted_j"])
+    assert bits_equal(coo["a"], g["coo_sorted_a"])
+    m.free()
+
+
+def test_csr_scalar_bitwise(g):
+    m = Matrix.csr(int(g["rows"]), int(g["cols"]), coo_of(g, "in"), 1, S.F64, S.CSR_SCALAR)
+    assert bits_equal(m.download(S.ARR_ROW_PTR), g["csr1_row_ptr"])
+    assert bits_equal(m.download(S.ARR_COL), g["csr1_col"])
+    assert bits_equal(m.download(S.ARR_VAL), g["csr1_val"])
+    y = m.mult(g["x"])
+    assert bits_equal(y, g["y_csr_base"])
+    assert bits_equal(y, g["y_coo"])            # the driver's own check (driver_spmv.c:274-289)
+
+
+@pytest.mark.parametrize("lanes", [0, 2, 4, 8, 16, 32, 64])
+def test_csr_vector(orc, g, lanes):
+    # alignment 4 = the reference's csr_vec mode (driver_spmv.c:189-191)
+    m = Matrix.csr(int(g["rows"]), int(g["cols"]), coo_of(g), 4, S.F64, S.CSR_VECTOR, lanes)
+    assert bits_equal(m.download(S.ARR_ROW_PTR), g["csr4_row_ptr"])
+    assert bits_equal(m.download(S.ARR_COL), g["csr4_col"])
+    assert bits_equal(m.download(S.ARR_VAL), g["csr4_val"])
+    y = m.mult(g["x"])
+    assert rel(orc, y, g["y_csr_base"]) <= TOL_REASSOC
+    assert rel(orc, y, g["y_csr_vec"]) <= TOL_REASSOC
+
+
+@pytest.mark.parametrize("items", [0, 4 * 256, 16 * 256])
+def test_csr_merge(orc, g, items):
+    rows = int(g["rows"])
+    m = Matrix.csr_merge(rows, int(g["cols"]), coo_of(g), S.F64, items)
+    info = m.info
+    rp = g["csr1_row_ptr"]
+    nnz = len(g["csr1_col"])
+    coords = m.download(S.ARR_TILE_COORD).reshape(-1, 2)
+    assert info.ntiles == -(-(rows + nnz) // info.items_per_tile)
+    for t in range(info.ntiles + 1):               # csr_merge.c:25-30 on tile diagonals
+        d = min(t * info.items_per_tile, rows + nnz)
+        assert tuple(coords[t]) == orc.merge_path_search(d, rp, nnz)
+    y = m.mult(g["x"])
+    assert rel(orc, y, g["y_csr_base"]) <= TOL_REASSOC
+    assert rel(orc, y, g["y_csr_merge_t8"]) <= TOL_REASSOC
+
+
+@pytest.mark.parametrize("chunk", [0, 4 * 256])
+def test_csr_bal_handles_empty_rows_too(orc, g, chunk):
+    m = Matrix.csr_bal(int(g["rows"]), int(g["cols"]), coo_of(g), S.F64, chunk)
+    y = m.mult(g["x"])
+    assert not np.isnan(y).any()
+    assert rel(orc, y, g["y_csr_base"]) <= TOL_REASSOC
+    if "y_csr_bal_t8" in g:
+        assert rel(orc, y, g["y_csr_bal_t8"]) <= TOL_REASSOC
+
+
+@pytest.mark.parametrize("sigma", CS.SELL_SIGMAS)
+def test_sell_layout_and_product(g, sigma):
+    rows = int(g["rows"])
+    m = Matrix.sell(rows, int(g["cols"]), g["csr1_row_ptr"], g["csr1_col"], g["csr1_val"], S.F64, 64, sigma)
+    assert m.info.slice_height == 64 and m.info.sigma == sigma
+    assert bits_equal(m.download(S.ARR_ROW_ORDER), g[f"sell_s{sigma}_row_order"])
+    assert bits_equal(m.download(S.ARR_SLICE_PTR), g[f"sell_s{sigma}_slice_ptr"])
+    assert bits_equal(m.download(S.ARR_COL), g[f"sell_s{sigma}_col"])
+    assert bits_equal(m.download(S.ARR_VAL), g[f"sell_s{sigma}_val"])
+    y = m.mult(g["x"])
+    assert bits_equal(y, g["y_csr_base"])
+    if f"y_sell_s{sigma}" in g:
+        assert bits_equal(y, g[f"y_sell_s{sigma}"])
+
+
+@pytest.mark.parametrize("height", [4, 64, 16])
+def test_sellp(g, orc, height):
+    rows = int(g["rows"])
+    m = Matrix.sellp(rows, int(g["cols"]), g["csr1_row_ptr"], g["csr1_col"], g["csr1_val"], S.F64, height)
+    if height == 4:                                 # the reference's _BLOCK (AVX2)
+        assert bits_equal(m.download(S.ARR_SLICE_PTR), g["sellp4_block_ptr"])
+        assert bits_equal(m.download(S.ARR_COL), g["sellp4_j"])
+        assert bits_equal(m.download(S.ARR_VAL), g["sellp4_A"])
+    else:
+        E = orc.sliced_ell_from_csr(g["csr1_row_ptr"], g["csr1_col"], g["csr1_val"], height)
+        assert bits_equal(m.download(S.ARR_SLICE_PTR), E["block_ptr"])
+        assert bits_equal(m.download(S.ARR_COL), E["j"])
+        assert bits_equal(m.download(S.ARR_VAL), E["A"])
+    y = m.mult(g["x"])
+    assert bits_equal(y, g["y_csr_base"])
+    assert bits_equal(y, g["y_sellp_autovec"])
+
+
+@pytest.mark.parametrize("height", [4, 0])
+def test_ell(g, height):
+    m = Matrix.ell(int(g["rows"]), int(g["cols"]), coo_of(g, "in"), S.F64, height)
+    if height == 4:                                 # SIMD_WIDTH of ell.c:4; reference j is int64
+        assert bits_equal(m.download(S.ARR_SLICE_PTR), g["ell4_block_ptr"])
+        assert bits_equal(m.download(S.ARR_COL).astype(np.int64), g["ell4_j"])
+        assert bits_equal(m.download(S.ARR_VAL), g["ell4_A"])
+    else:
+        assert m.info.slice_height == 64
+    y = m.mult(g["x"])
+    assert bits_equal(y, g["y_ell"])
+
+
+FP32_BUILDERS = {
+    "csr_scalar": lambda r, c, coo, csr: Matrix.csr(r, c, coo, 1, S.F32, S.CSR_SCALAR),
+    "csr_vector": lambda r, c, coo, csr: Matrix.csr(r, c, coo, 1, S.F32, S.CSR_VECTOR),
+    "csr_merge": lambda r, c, coo, csr: Matrix.csr_merge(r, c, coo, S.F32),
+    "csr_bal": lambda r, c, coo, csr: Matrix.csr_bal(r, c, coo, S.F32),
+    "sell": lambda r, c, coo, csr: Matrix.sell(r, c, *csr, S.F32, 64, 1024),
+    "sellp": lambda r, c, coo, csr: Matrix.sellp(r, c, *csr, S.F32),
+    "ell": lambda r, c, coo, csr: Matrix.ell(r, c, coo, S.F32),
+}
+
+
+@pytest.mark.parametrize("fmt", sorted(FP32_BUILDERS))
+def test_fp32(orc, g, fmt):
+    rows, cols = int(g["rows"]), int(g["cols"])
+    csr = (g["csr1_row_ptr"], g["csr1_col"], g["csr1_val"])
+    m = FP32_BUILDERS[fmt](rows, cols, coo_of(g), csr)
+    assert m.info.dtype == S.F32
+    x32 = g["x"].astype(np.float32)
+    y = m.mult(x32.astype(np.float64))
+    y32 = orc.mult_csr_base_f32(csr[0], csr[1], csr[2].astype(np.float32), x32)
+    if fmt in ("csr_scalar", "sell", "sellp", "ell"):
+        assert bits_equal(y.astype(np.float32), y32)
+    else:
+        assert rel(orc, y, y32) <= TOL_F32_VS_F32
+    assert rel(orc, y, g["y_csr_base"]) <= TOL_F32_VS_F64
+
+
+def test_modes_of_the_reference_driver(orc, g):
+    """MODE strings of driver_spmv.c:186-261 each give y == y_ref within its bar (:313)."""
+    rows, cols = int(g["rows"]), int(g["cols"])
+    for mode in S.MODES:
+        m = S.create(mode, rows, cols, coo_of(g, "in"))
+        y = m.mult(g["x"])
+        assert rel(orc, y, g["y_coo"]) <= TOL_REASSOC, mode
+        m.free()
+    with pytest.raises(ValueError):
+        S.create("no_such_mode", rows, cols, coo_of(g))
+
+
+def test_device_resident_path(orc, g):
+    """CSR handed over in HBM, x/y resident, launches on torch's stream."""
+    import torch
+    rows, cols = int(g["rows"]), int(g["cols"])
+    dev = torch.device("cuda:0")
+    rp = torch.from_numpy(g["csr1_row_ptr"]).to(dev)
+    cj = torch.from_numpy(g["csr1_col"]).to(dev)
+    va = torch.from_numpy(g["csr1_val"]).to(dev)
+    if cj.numel() == 0:
+        cj = torch.zeros(1, dtype=torch.int32, device=dev); va = torch.zeros(1, dtype=torch.float64, device=dev)
+    x = torch.from_numpy(g["x"]).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    nnz = len(g["csr1_col"])
+    for fmt, p0, p1, exact in [(S.CSR_SCALAR, 0, 0, True), (S.CSR_VECTOR, 0, 0, False), (S.CSR_MERGE, 0, 0, False),
+                               (S.CSR_BAL, 0, 0, False), (S.SELL, 64, 1024, True), (S.SELLP, 0, 0, True),
+                               (S.ELL, 0, 0, True)]:
+        m = Matrix.from_device_csr(fmt, rows, cols, nnz, rp.data_ptr(), cj.data_ptr(), va.data_ptr(), S.F64, p0, p1, st,
+                                   keepalive=(rp, cj, va))
+        y = torch.full((max(rows, 1),), float("nan"), dtype=torch.float64, device=dev)
+        m.mult_dev(x.data_ptr(), y.data_ptr(), st)
+        torch.cuda.synchronize()
+        yh = y[:rows].cpu().numpy()
+        if exact:
+            assert bits_equal(yh, g["y_csr_base"]), S.FORMAT_NAMES[fmt]
+        else:
+            assert rel(orc, yh, g["y_csr_base"]) <= TOL_REASSOC, S.FORMAT_NAMES[fmt]
+        m.free()
+
+
+def test_norm_and_scale_match_driver(orc, g):
+    import ctypes as C
+    import torch
+    n = int(g["cols"])
+    dev = torch.device("cuda:0")
+    v = torch.from_numpy(g["x"] * 3.0 + 0.25).to(dev)
+    out = torch.zeros(1, dtype=torch.float64, device=dev)
+    xs = torch.empty_like(v)
+    L = S.lib()
+    assert L.spmv_hip_norm2_dev(n, v.data_ptr(), S.F64, out.data_ptr(), 0) == 0
+    assert L.spmv_hip_scale_dev(n, v.data_ptr(), xs.data_ptr(), S.F64, out.data_ptr(), 0) == 0
+    torch.cuda.synchronize()
+    want = orc.lib().orc_vec_norm(n, np.ascontiguousarray(v.cpu().numpy()))     # driver_spmv.c:21-26
+    assert abs(out.item() - want) <= 1e-14 * max(want, 1.0)
+    np.testing.assert_allclose(xs.cpu().numpy(), v.cpu().numpy() / out.item(), rtol=1e-15, atol=0)
+
+
+def test_bench_loop_is_the_drivers_power_iteration(orc, g):
+    rows, cols = int(g["rows"]), int(g["cols"])
+    if rows != cols or len(g["csr1_col"]) == 0:
+        pytest.skip("power loop needs a square non-empty matrix (driver_spmv.c:176)")
+    m = Matrix.sell(rows, cols, g["csr1_row_ptr"], g["csr1_col"], g["csr1_val"], S.F64, 64, 1024)
+    iters, seconds, gflops, x_last = m.bench(g["x"], min_iters=10, min_seconds=0.0)
+    assert iters == 10 and seconds > 0 and gflops > 0
+    # replay driver_spmv.c:295-302 on the oracle
+    x = g["x"].copy()
+    for _ in range(iters):
+        y = orc.mult_csr_base(g["csr1_row_ptr"], g["csr1_col"], g["csr1_val"], x)
+        nrm = orc.lib().orc_vec_norm(rows, y)
+        if nrm == 0:
+            pytest.skip("iterate vanished")
+        x = y / nrm
+    assert rel(orc, x_last, x) <= 1e-12
+
+
+def test_errors_are_reported_not_fatal():
+    coo = S.make_coo([0, 1], [0, 5], [1.0, 2.0])
+    with pytest.raises(S.SpmvHipError, match="column index"):
+        Matrix.csr(2, 2, coo)
+    rp = np.array([0, 1, 2], np.int32); cj = np.array([0, 1], np.int32); va = np.ones(2)
+    with pytest.raises(S.SpmvHipError, match="multiple of C"):
+        Matrix.sell(2 * 100, 200, np.arange(201, dtype=np.int32), np.arange(200, dtype=np.int32), np.ones(200),
+                    S.F64, 64, 100)
+    with pytest.raises(S.SpmvHipError, match="power of two"):
+        Matrix.sellp(2, 2, rp, cj, va, S.F64, 3)
+    with pytest.raises(S.SpmvHipError, match="tile size"):
+        Matrix.csr_merge(2, 2, S.make_coo([0, 1], [0, 1], [1.0, 2.0]), S.F64, 1000)
