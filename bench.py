@@ -169,6 +169,7 @@ def main():
     if world == 1:
         m = Matrix.from_device_csr(fmt, rows, cols, nnz, rp.data_ptr(), cj.data_ptr(), va.data_ptr(), dtype, p0, p1,
                                    stream, keepalive=(rp, cj, va))
+        m.analyze(3)           # kernel variant by trial, as create_sell does (reference sell.c:30)
         if fmt in (S.SELL, S.SELLP, S.ELL):
             m._keepalive = None
             del rp, cj, va
@@ -181,7 +182,7 @@ def main():
         def step():
             m.mult_dev(x.data_ptr(), y.data_ptr(), stream)
         info = m.info
-        stored = info.stored
+        stored, variant = info.stored, info.variant
         global_rows, global_nnz, global_cols = rows, nnz, cols
     else:
         from spmv_amd.distributed import RowBlockSpmv
@@ -195,7 +196,7 @@ def main():
 
         def step():
             op.mult(x, y)
-        stored = op.stored
+        stored, variant = op.stored, op.variant
         global_rows, global_nnz, global_cols = rows * world, None, cols
         t = torch.tensor([nnz], dtype=torch.int64, device=dev)
         dist.all_reduce(t)
@@ -244,7 +245,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload, "format": args.format,
                        "params": {"C": 64, "sigma": args.sigma} if fmt == S.SELL else {"p0": p0},
-                       "rows": global_rows, "nnz": global_nnz, "stored_per_gpu": int(stored),
+                       "rows": global_rows, "nnz": global_nnz, "stored_per_gpu": int(stored), "kernel_variant": variant,
                        "exchange": args.exchange if world > 1 else None},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

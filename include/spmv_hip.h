@@ -71,6 +71,7 @@ typedef struct spmv_hip_info {
     int     ntiles;       /* CSR_MERGE / CSR_BAL workgroup tiles; 0 otherwise         */
     int     items_per_tile;
     int64_t device_bytes; /* HBM held by the handle                                   */
+    int     variant;      /* kernel variant in use (spmv_hip_set_option / spmv_hip_analyze) */
 } spmv_hip_info;
 
 /* Selects the device for subsequent creators on this thread (hipSetDevice). */
@@ -165,6 +166,16 @@ int spmv_hip_bench(spmv_hip_matrix *m, int min_iters, double min_seconds, double
 int spmv_hip_norm2_dev(int n, const void *d_x, int dtype, double *d_out, void *stream);
 /* d_x[i] = d_y[i] / *d_norm */
 int spmv_hip_scale_dev(int n, const void *d_y, void *d_x, int dtype, const double *d_norm, void *stream);
+
+/* ---- tuning (counterpart of sellcs_analyze_matrix, sellcs_analyzer.c:46-120:
+ * pick the launch shape by trial).  Options: "variant" = kernel variant of the
+ * handle's format (0 = default). */
+int spmv_hip_set_option(spmv_hip_matrix *m, const char *name, int64_t value);
+/* sellcs_analyze_matrix (sell.c:30, sellcs_analyzer.c:46-120) re-thought for the
+ * GPU: times every kernel variant of the handle's format `reps` times on a
+ * zero vector and keeps the fastest.  Variant 0 of the sliced formats keeps
+ * mult_csr_base's summation order (bit-identical y); the others reassociate. */
+int spmv_hip_analyze(spmv_hip_matrix *m, int reps);
 
 /* ---- introspection for layout-parity tests ---------------------------------- */
 int spmv_hip_get_info(const spmv_hip_matrix *m, spmv_hip_info *info);

@@ -24,7 +24,8 @@ class Info(C.Structure):
     _fields_ = [("format", C.c_int), ("dtype", C.c_int), ("rows", C.c_int), ("columns", C.c_int),
                 ("nnz", C.c_int64), ("stored", C.c_int64), ("slice_height", C.c_int),
                 ("sigma", C.c_int64), ("nslices", C.c_int), ("lanes_per_row", C.c_int),
-                ("ntiles", C.c_int), ("items_per_tile", C.c_int), ("device_bytes", C.c_int64)]
+                ("ntiles", C.c_int), ("items_per_tile", C.c_int), ("device_bytes", C.c_int64),
+                ("variant", C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/spmv_hip.h declares
@@ -48,6 +49,8 @@ SIGNATURES = {
     "spmv_hip_bench": (_i, [_vp, _i, C.c_double, _vp, C.POINTER(_i), C.POINTER(C.c_double)]),
     "spmv_hip_norm2_dev": (_i, [_i, _vp, _i, _vp, _vp]),
     "spmv_hip_scale_dev": (_i, [_i, _vp, _vp, _i, _vp, _vp]),
+    "spmv_hip_set_option": (_i, [_vp, C.c_char_p, _i64]),
+    "spmv_hip_analyze": (_i, [_vp, _i]),
     "spmv_hip_get_info": (_i, [_vp, C.POINTER(Info)]),
     "spmv_hip_download": (_i, [_vp, _i, _vp, C.c_size_t]),
 }

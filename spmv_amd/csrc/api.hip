@@ -383,6 +383,52 @@ int spmv_hip_scale_dev(int n, const void *d_y, void *d_x, int dtype, const doubl
     return launch_scale(n, d_y, d_x, dtype, d_norm, (hipStream_t)stream);
 }
 
+int spmv_hip_set_option(spmv_hip_matrix *m, const char *name, int64_t value)
+{
+    clear_error();
+    if (!m || !name) { set_error("NULL argument"); return 1; }
+    if (!strcmp(name, "variant")) { m->variant = (int)value; return 0; }
+    set_error("unknown option '%s'", name);
+    return 1;
+}
+
+int spmv_hip_analyze(spmv_hip_matrix *m, int reps)
+{
+    clear_error();
+    if (!m) { set_error("NULL handle"); return 1; }
+    if (reps < 1) reps = 3;
+    int cand[32];
+    const int n = variant_candidates(m, cand, 32);
+    if (n <= 1 || m->rows == 0) return 0;
+    if (ensure_vectors(m)) return 1;
+    const size_t es = dtype_size(m->dtype);
+    SPMV_HIP_TRY(hipMemset(m->d_x, 0, (size_t)std::max(m->columns, 1) * es), return 1);
+    hipEvent_t e0, e1;
+    SPMV_HIP_TRY(hipEventCreate(&e0), return 1);
+    SPMV_HIP_TRY(hipEventCreate(&e1), return 1);
+    const int keep = m->variant;
+    int best = keep, rc = 0;
+    float best_ms = 0;
+    for (int i = 0; i < n && !rc; i++) {
+        m->variant = cand[i];
+        if (launch_mult(m, m->d_x, m->d_y, nullptr)) { rc = 1; break; }          // warm-up
+        float total = 0;
+        for (int r = 0; r < reps; r++) {
+            if (hipEventRecord(e0, nullptr) != hipSuccess || launch_mult(m, m->d_x, m->d_y, nullptr) ||
+                hipEventRecord(e1, nullptr) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) { rc = 1; break; }
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = 1; break; }
+            total += ms;
+        }
+        if (!rc && (i == 0 || total < best_ms)) { best_ms = total; best = cand[i]; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    m->variant = rc ? keep : best;
+    if (rc && !g_error[0]) set_error("analyze: timing a kernel variant failed");
+    return rc;
+}
+
 int spmv_hip_get_info(const spmv_hip_matrix *m, spmv_hip_info *info)
 {
     if (!m || !info) { set_error("NULL argument"); return 1; }
@@ -394,6 +440,7 @@ int spmv_hip_get_info(const spmv_hip_matrix *m, spmv_hip_info *info)
     info->lanes_per_row = m->lanes_per_row;
     info->ntiles = m->ntiles; info->items_per_tile = m->items_per_tile;
     info->device_bytes = m->device_bytes;
+    info->variant = m->variant;
     return 0;
 }
 

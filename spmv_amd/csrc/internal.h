@@ -45,6 +45,7 @@ struct spmv_hip_matrix {
     int *d_col = nullptr;
     void *d_val = nullptr;
     int lanes_per_row = 0;
+    int variant = 0;               // kernel variant inside the format (spmv_hip_set_option "variant")
 
     // merge-path / balanced tiles
     int ntiles = 0, items_per_tile = 0;
@@ -76,6 +77,7 @@ namespace spmv {
 
 // kernels.hip -- asynchronous launches on `stream`
 int launch_mult(const spmv_hip_matrix *m, const void *d_x, void *d_y, hipStream_t stream);
+int variant_candidates(const spmv_hip_matrix *m, int *out, int max_out);
 int launch_norm2(int n, const void *d_x, int dtype, double *d_out, hipStream_t stream);
 int launch_scale(int n, const void *d_y, void *d_x, int dtype, const double *d_norm, hipStream_t stream);
 
@@ -87,7 +89,6 @@ int build_merge_tiles(spmv_hip_matrix *m, hipStream_t stream);
 int build_bal_tiles(spmv_hip_matrix *m, hipStream_t stream);
 int build_sliced(spmv_hip_matrix *m, const int *d_row_ptr, const int *d_col, const void *d_val,
                  bool val_is_f64, bool sorted, hipStream_t stream);
-int convert_f64_to_f32(int64_t n, const double *d_in, float *d_out, hipStream_t stream);
 
 template <typename T> int dev_alloc(spmv_hip_matrix *m, T **p, size_t count)
 {

@@ -101,11 +101,14 @@ __global__ __launch_bounds__(kBlock) void csr_vector_kernel(int rows, const int 
 }
 
 // ------------------------------------------- sliced formats, slice height 64 --
-// One wave per slice, lane = row of the slice.  Slice storage is column-major
-// (reference sellcs_format.c:174-187, sellp.c:440-452): entry j of lane k sits
-// at slice_ptr[s] + j*64 + k, so every wave load is one contiguous 512-byte
-// (values, fp64) or 256-byte (columns) run.  U independent columns are loaded
-// before their gathers so that U*768 bytes per wave are in flight.
+// One wave per slice.  Slice storage is column-major (reference
+// sellcs_format.c:174-187, sellp.c:440-452): entry j of row k of the slice sits
+// at slice_ptr[s] + j*64 + k, so a wave reads whole columns as contiguous runs.
+//
+// sliced64_kernel ("exact"): lane = row, one fma per column in ascending column
+// order -- the summation order of mult_csr_base (reference csr.c:4-13) and of
+// sellcs_mv_d_autovector (sellcs_mv_autovector.c:40-52), so y is bit-identical
+// to both.  U columns (U*768 bytes per wave, fp64) are in flight per batch.
 
 template <typename T, bool PERM, int U>
 __global__ __launch_bounds__(kBlock) void sliced64_kernel(int rows, int nslices,
@@ -140,6 +143,74 @@ __global__ __launch_bounds__(kBlock) void sliced64_kernel(int rows, int nslices,
     for (; j < width; j++) acc = fma_t(x[c[(int64_t)j * kWave]], v[(int64_t)j * kWave], acc);
     int r = s * kWave + lane;
     if (r < rows) y[PERM ? row_order[r] : r] = acc;
+}
+
+// sliced64_wide_kernel: the same slices read with 16-byte loads.  Lane l =
+// (h = l / HL, q = l % HL) holds the R = 16/sizeof(T) adjacent rows q*R..q*R+R-1
+// of column P*jj + h, so one wave instruction moves P = R whole columns (1 KiB
+// of values).  A batch of U such steps is loaded, gathered and accumulated at
+// once: with U*P >= slice width the whole slice costs one streaming round trip
+// and one gather round trip.  Each lane sums the columns == h (mod P) of its
+// rows; the P partial sums of a row are then added across the lane groups, so
+// the in-row order differs from mult_csr_base (parity by tolerance, not bits).
+// Columns past the slice width are read from the last column (no extra HBM
+// traffic) and multiplied by zero.
+template <typename T, bool PERM, int U, bool NT>
+__global__ __launch_bounds__(kBlock) void sliced64_wide_kernel(int rows, int nslices,
+                                                               const int64_t *__restrict__ slice_ptr,
+                                                               const int *__restrict__ row_order,
+                                                               const int *__restrict__ scol,
+                                                               const T *__restrict__ sval,
+                                                               const T *__restrict__ x, T *__restrict__ y)
+{
+    constexpr int R = 16 / sizeof(T);        // rows per lane: 2 (fp64), 4 (fp32)
+    constexpr int HL = kWave / R;            // lanes per column: 32, 16
+    constexpr int P = R;                     // columns per wave instruction: 2, 4
+    typedef T TV __attribute__((ext_vector_type(R)));
+    typedef int IV __attribute__((ext_vector_type(R)));
+    unsigned b = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    int s = __builtin_amdgcn_readfirstlane((int)(b * (kBlock / kWave) + threadIdx.x / kWave));
+    if (s >= nslices) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int h = lane / HL, q = lane % HL;
+    int64_t base = slice_ptr[s];
+    const int width = (int)((slice_ptr[s + 1] - base) >> 6);
+    const T *v = sval + base + q * R;
+    const int *c = scol + base + q * R;
+    TV acc = (TV)(0);
+    const int steps = (width + P - 1) / P;
+    for (int jj = 0; jj < steps; jj += U) {
+        IV cc[U];
+        TV vv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const IV *p = (const IV *)(c + (int64_t)min(P * (jj + u) + h, width - 1) * kWave);
+            cc[u] = NT ? __builtin_nontemporal_load(p) : *p;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const TV *p = (const TV *)(v + (int64_t)min(P * (jj + u) + h, width - 1) * kWave);
+            vv[u] = NT ? __builtin_nontemporal_load(p) : *p;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const bool live = P * (jj + u) + h < width;
+#pragma unroll
+            for (int k = 0; k < R; k++) acc[k] = fma_t(x[cc[u][k]], live ? vv[u][k] : (T)0, acc[k]);
+        }
+    }
+    // add the P column groups, then hand row l to lane l for one coalesced store
+    T mine = 0;
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        T t = acc[k];
+        if (P >= 4) t += __shfl_xor(t, 16, kWave);
+        t += __shfl_xor(t, 32, kWave);
+        T from = __shfl(t, lane / R, kWave);
+        if ((lane % R) == k) mine = from;
+    }
+    int r = s * kWave + lane;
+    if (r < rows) y[PERM ? row_order[r] : r] = mine;
 }
 
 // ------------------------------------- sliced formats, any slice height <= 64 --
@@ -369,19 +440,57 @@ template <typename T> static int launch_csr_vector(const spmv_hip_matrix *m, con
     return 0;
 }
 
+// variant 0 = exact-order kernel; 1..4 = 16-byte-load kernel with 2, 4, 7, 14 steps
+// per batch (fp64: 4, 8, 14, 28 columns; fp32: 8, 16, 28, 56); +8 = the same with
+// non-temporal loads of the streamed arrays.
+constexpr int kSlicedVariants[] = {0, 1, 2, 3, 4, 9, 10, 11, 12};
+
+int variant_candidates(const spmv_hip_matrix *m, int *out, int max_out)
+{
+    int n = 0;
+    const bool sliced64 = m->d_slice_ptr && m->slice_height == kWave;
+    if (sliced64) {
+        for (int v : kSlicedVariants)
+            if (n < max_out) out[n++] = v;
+    } else if (n < max_out) {
+        out[n++] = 0;
+    }
+    return n;
+}
+
+template <typename T, bool PERM>
+static int launch_sliced64(const spmv_hip_matrix *m, const T *x, T *y, hipStream_t st)
+{
+    dim3 grid(cdiv(m->nslices, kBlock / kWave)), block(kBlock);
+    const T *sv = (const T *)m->d_sval;
+#define SPMV_WIDE(U, NT)                                                                                   \
+    hipLaunchKernelGGL((sliced64_wide_kernel<T, PERM, U, NT>), grid, block, 0, st, m->rows, m->nslices,    \
+                       m->d_slice_ptr, m->d_row_order, m->d_scol, sv, x, y)
+    switch (m->variant) {
+    case 0:
+        hipLaunchKernelGGL((sliced64_kernel<T, PERM, 8>), grid, block, 0, st, m->rows, m->nslices, m->d_slice_ptr,
+                           m->d_row_order, m->d_scol, sv, x, y);
+        break;
+    case 1: SPMV_WIDE(2, false); break;
+    case 2: SPMV_WIDE(4, false); break;
+    case 3: SPMV_WIDE(7, false); break;
+    case 4: SPMV_WIDE(14, false); break;
+    case 9: SPMV_WIDE(2, true); break;
+    case 10: SPMV_WIDE(4, true); break;
+    case 11: SPMV_WIDE(7, true); break;
+    case 12: SPMV_WIDE(14, true); break;
+    default: set_error("sliced format: unknown kernel variant %d", m->variant); return 1;
+    }
+#undef SPMV_WIDE
+    return 0;
+}
+
 template <typename T> static int launch_sliced(const spmv_hip_matrix *m, const T *x, T *y, hipStream_t st)
 {
     const T *sv = (const T *)m->d_sval;
     const bool perm = m->d_row_order != nullptr;
     if (m->slice_height == kWave) {
-        dim3 grid(cdiv(m->nslices, kBlock / kWave));
-        constexpr int U = sizeof(T) == 8 ? 8 : 8;
-        if (perm)
-            hipLaunchKernelGGL((sliced64_kernel<T, true, U>), grid, dim3(kBlock), 0, st, m->rows, m->nslices,
-                               m->d_slice_ptr, m->d_row_order, m->d_scol, sv, x, y);
-        else
-            hipLaunchKernelGGL((sliced64_kernel<T, false, U>), grid, dim3(kBlock), 0, st, m->rows, m->nslices,
-                               m->d_slice_ptr, m->d_row_order, m->d_scol, sv, x, y);
+        return perm ? launch_sliced64<T, true>(m, x, y, st) : launch_sliced64<T, false>(m, x, y, st);
     } else {
         dim3 grid(cdiv(m->rows, kBlock));
         if (perm)

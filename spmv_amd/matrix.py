@@ -102,6 +102,16 @@ class Matrix:
         gflops = 2.0 * self.info.nnz * it.value / sec.value / 1e9
         return it.value, sec.value, gflops, x
 
+    def set_option(self, name: str, value: int) -> None:
+        L.check(L.lib().spmv_hip_set_option(self._h, name.encode(), value))
+        self._info = None
+
+    def analyze(self, reps: int = 3) -> int:
+        """Pick the fastest kernel variant by trial (sellcs_analyze_matrix, sell.c:30); returns it."""
+        L.check(L.lib().spmv_hip_analyze(self._h, reps))
+        self._info = None
+        return self.info.variant
+
     @property
     def info(self) -> L.Info:
         if self._info is None:

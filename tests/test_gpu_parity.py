@@ -114,6 +114,34 @@ def test_sell_layout_and_product(g, sigma):
         assert bits_equal(y, g[f"y_sell_s{sigma}"])
 
 
+SLICED_VARIANTS = [1, 2, 3, 4, 9, 10, 11, 12]
+
+
+@pytest.mark.parametrize("fmt", ["sell", "sellp"])
+def test_sliced_wide_variants_and_analyze(orc, g, fmt):
+    """16-byte-load kernels reassociate the row sums: tolerance parity; analyze() picks one of them or 0."""
+    rows, cols = int(g["rows"]), int(g["cols"])
+    csr = (g["csr1_row_ptr"], g["csr1_col"], g["csr1_val"])
+    for dtype, tol, ref in ((S.F64, TOL_REASSOC, g["y_csr_base"]),
+                            (S.F32, TOL_F32_VS_F32, orc.mult_csr_base_f32(csr[0], csr[1], csr[2].astype(np.float32),
+                                                                          g["x"].astype(np.float32)))):
+        m = Matrix.sell(rows, cols, *csr, dtype, 64, 1024) if fmt == "sell" else Matrix.sellp(rows, cols, *csr, dtype, 64)
+        xin = g["x"].astype(np.float32).astype(np.float64) if dtype == S.F32 else g["x"]
+        for v in SLICED_VARIANTS:
+            m.set_option("variant", v)
+            assert m.info.variant == v
+            y = m.mult(xin)
+            assert not np.isnan(y).any()
+            assert rel(orc, y, ref) <= tol, (v, dtype)
+        chosen = m.analyze(2)
+        assert chosen in [0] + SLICED_VARIANTS
+        assert rel(orc, m.mult(xin), ref) <= tol
+        with pytest.raises(S.SpmvHipError, match="variant"):
+            m.set_option("variant", 99)
+            m.mult(xin)
+        m.free()
+
+
 @pytest.mark.parametrize("height", [4, 64, 16])
 def test_sellp(g, orc, height):
     rows = int(g["rows"])

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Time the kernel variants of one format on a synthetic workload (one GPU).
+
+    python tools/tune.py --format sell --matrix stencil27 --n 252 --variants 0,1,2
+
+Prints per variant: median/min kernel ms (HIP events on the launch stream),
+algorithmic GB/s, and rel-L2 difference of y against variant 0.
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+
+import torch  # noqa: E402
+
+import spmv_amd as S  # noqa: E402
+from spmv_amd import generators as G  # noqa: E402
+from spmv_amd.matrix import Matrix  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--format", default="sell")
+    ap.add_argument("--matrix", default="stencil27")
+    ap.add_argument("--n", type=int, default=252)
+    ap.add_argument("--dtype", default="f64")
+    ap.add_argument("--sigma", type=int, default=1024)
+    ap.add_argument("--p0", default="0", help="comma list of p0 values (lanes / tile size / slice height)")
+    ap.add_argument("--variants", default="0")
+    ap.add_argument("--steps", type=int, default=20)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    dtype = S.F64 if args.dtype == "f64" else S.F32
+    td = torch.float64 if dtype == S.F64 else torch.float32
+    vb = 8 if dtype == S.F64 else 4
+    if args.matrix == "stencil27":
+        rows, cols, rp, cj, va = G.stencil27(args.n, device=dev)
+    elif args.matrix == "laplacian2d":
+        rows, cols, rp, cj, va = G.laplacian2d(args.n, device=dev)
+    else:
+        rows, cols, rp, cj, va = G.rmat(args.n, 16, device=dev)
+    va = va.to(td)
+    nnz = int(rp[-1])
+    b_alg = nnz * (vb + 4) + rows * (4 + vb) + cols * vb
+    fmt = {"sell": S.SELL, "sellp": S.SELLP, "ell": S.ELL, "csr_scalar": S.CSR_SCALAR, "csr_vector": S.CSR_VECTOR,
+           "csr_merge": S.CSR_MERGE, "csr_bal": S.CSR_BAL}[args.format]
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = torch.rand(cols, dtype=td, device=dev, generator=g)
+    y = torch.empty(rows, dtype=td, device=dev)
+    y0 = None
+    print(f"# {args.format} {args.matrix} n={args.n} {args.dtype}: rows {rows} nnz {nnz} B_alg {b_alg / 1e9:.3f} GB")
+    for p0 in [int(v) for v in args.p0.split(",")]:
+        pp0 = p0 or (64 if fmt == S.SELL else 0)
+        m = Matrix.from_device_csr(fmt, rows, cols, nnz, rp.data_ptr(), cj.data_ptr(), va.data_ptr(), dtype, pp0,
+                                   args.sigma if fmt == S.SELL else 0, st)
+        for var in [int(v) for v in args.variants.split(",")]:
+            m.set_option("variant", var)
+            for _ in range(3):
+                m.mult_dev(x.data_ptr(), y.data_ptr(), st)
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+            for a, b in ev:
+                a.record(); m.mult_dev(x.data_ptr(), y.data_ptr(), st); b.record()
+            torch.cuda.synchronize()
+            ms = sorted(a.elapsed_time(b) for a, b in ev)
+            if y0 is None:
+                y0 = y.clone()
+            err = float(torch.linalg.vector_norm(y - y0) / torch.linalg.vector_norm(y0))
+            med = ms[len(ms) // 2]
+            print(f"p0={p0:6d} variant={var:3d}  median {med:8.4f} ms  min {ms[0]:8.4f} ms  "
+                  f"{b_alg / med / 1e6:8.1f} GB/s alg ({b_alg / med / 1e6 / 80:.1f}% of 8 TB/s)  "
+                  f"{2 * nnz / med / 1e6:8.1f} GFLOP/s  stored {m.info.stored}  relerr-vs-first {err:.2e}", flush=True)
+        m.free()
+
+
+if __name__ == "__main__":
+    main()
