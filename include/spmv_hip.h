@@ -150,6 +150,13 @@ int spmv_hip_mult(spmv_hip_matrix *m, const double *x, double *y);
  * (a hipStream_t; NULL = default stream).  Asynchronous. */
 int spmv_hip_mult_dev(spmv_hip_matrix *m, const void *d_x, void *d_y, void *stream);
 
+/* Row map for a CSR_SCALAR / CSR_VECTOR handle whose rows are a compacted
+ * subset of a larger vector: row k writes y[d_row_map[k]] (device array of
+ * `rows` ints, kept alive by the caller; NULL restores y[k]).  Used by the
+ * row-block multi-GPU layer for the rows that touch halo columns.  No reference
+ * counterpart (the reference has no partitioned product). */
+int spmv_hip_set_row_map(spmv_hip_matrix *m, const int *d_row_map);
+
 /* free_X (csr.c:205-210, sellp.c:461-465; the reference leaks the others) */
 int spmv_hip_free(spmv_hip_matrix *m);
 

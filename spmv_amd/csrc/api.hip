@@ -318,6 +318,7 @@ int spmv_hip_mult(spmv_hip_matrix *m, const double *x, double *y)
 {
     clear_error();
     if (!m || !x || !y) { set_error("NULL argument"); return 1; }
+    if (m->d_row_map) { set_error("row-mapped handles multiply through spmv_hip_mult_dev only"); return 1; }
     if (ensure_vectors(m)) return 1;
     if (upload_vector(m, m->d_x, x, m->columns)) return 1;
     if (launch_mult(m, m->d_x, m->d_y, nullptr)) return 1;
@@ -342,6 +343,7 @@ int spmv_hip_bench(spmv_hip_matrix *m, int min_iters, double min_seconds, double
     clear_error();
     if (!m || !x || !iters || !seconds) { set_error("NULL argument"); return 1; }
     if (m->rows != m->columns) { set_error("bench: matrix is not square"); return 1; }
+    if (m->d_row_map) { set_error("row-mapped handles multiply through spmv_hip_mult_dev only"); return 1; }
     if (ensure_vectors(m)) return 1;
     if (upload_vector(m, m->d_x, x, m->columns)) return 1;
     hipEvent_t e0, e1;
@@ -390,6 +392,18 @@ int spmv_hip_set_option(spmv_hip_matrix *m, const char *name, int64_t value)
     if (!strcmp(name, "variant")) { m->variant = (int)value; return 0; }
     set_error("unknown option '%s'", name);
     return 1;
+}
+
+int spmv_hip_set_row_map(spmv_hip_matrix *m, const int *d_row_map)
+{
+    clear_error();
+    if (!m) { set_error("NULL handle"); return 1; }
+    if (m->format != SPMV_HIP_CSR_SCALAR && m->format != SPMV_HIP_CSR_VECTOR) {
+        set_error("row map is only supported by CSR_SCALAR / CSR_VECTOR handles");
+        return 1;
+    }
+    m->d_row_map = d_row_map;
+    return 0;
 }
 
 int spmv_hip_analyze(spmv_hip_matrix *m, int reps)

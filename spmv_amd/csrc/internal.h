@@ -45,6 +45,7 @@ struct spmv_hip_matrix {
     int *d_col = nullptr;
     void *d_val = nullptr;
     int lanes_per_row = 0;
+    const int *d_row_map = nullptr; // CSR_SCALAR / CSR_VECTOR: matrix row k writes y[row_map[k]] (caller's array)
     int variant = 0;               // kernel variant inside the format (spmv_hip_set_option "variant")
 
     // merge-path / balanced tiles

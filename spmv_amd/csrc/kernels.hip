@@ -68,6 +68,7 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void csr_scalar_kernel(int rows, const int *__restrict__ row_ptr,
                                                             const int *__restrict__ col,
                                                             const T *__restrict__ val,
+                                                            const int *__restrict__ row_map,
                                                             const T *__restrict__ x, T *__restrict__ y)
 {
     unsigned b = xcd_contiguous_block(blockIdx.x, gridDim.x);
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(kBlock) void csr_scalar_kernel(int rows, const int 
     int beg = row_ptr[row], end = row_ptr[row + 1];
     T s = 0;
     for (int l = beg; l < end; l++) s = fma_t(x[col[l]], val[l], s);
-    y[row] = s;
+    y[row_map ? row_map[row] : row] = s;
 }
 
 // --------------------------------------------------------- CSR, G lanes/row --
@@ -85,6 +86,7 @@ template <typename T, int G>
 __global__ __launch_bounds__(kBlock) void csr_vector_kernel(int rows, const int *__restrict__ row_ptr,
                                                             const int *__restrict__ col,
                                                             const T *__restrict__ val,
+                                                            const int *__restrict__ row_map,
                                                             const T *__restrict__ x, T *__restrict__ y)
 {
     constexpr int kRowsPerBlock = kBlock / G;
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void csr_vector_kernel(int rows, const int 
         for (int l = beg + lane; l < end; l += G) s = fma_t(x[col[l]], val[l], s);
     }
     s = group_sum<G>(s);
-    if (lane == 0 && row < rows) y[row] = s;
+    if (lane == 0 && row < rows) y[row_map ? row_map[row] : row] = s;
 }
 
 // ------------------------------------------- sliced formats, slice height 64 --
@@ -423,7 +425,7 @@ template <typename T> static int launch_csr_vector(const spmv_hip_matrix *m, con
 #define SPMV_VEC_CASE(G)                                                                              \
     case G:                                                                                           \
         hipLaunchKernelGGL((csr_vector_kernel<T, G>), dim3(cdiv(rows, kBlock / G)), dim3(kBlock), 0,  \
-                           st, rows, rp, cj, va, x, y);                                               \
+                           st, rows, rp, cj, va, m->d_row_map, x, y);                                 \
         break;
     switch (m->lanes_per_row) {
         SPMV_VEC_CASE(2)
@@ -547,7 +549,7 @@ template <typename T> static int launch_mult_t(const spmv_hip_matrix *m, const T
     switch (m->format) {
     case SPMV_HIP_CSR_SCALAR:
         hipLaunchKernelGGL((csr_scalar_kernel<T>), dim3(cdiv(m->rows, kBlock)), dim3(kBlock), 0, st, m->rows,
-                           m->d_row_ptr, m->d_col, (const T *)m->d_val, x, y);
+                           m->d_row_ptr, m->d_col, (const T *)m->d_val, m->d_row_map, x, y);
         break;
     case SPMV_HIP_CSR_VECTOR: rc = launch_csr_vector<T>(m, x, y, st); break;
     case SPMV_HIP_CSR_MERGE:

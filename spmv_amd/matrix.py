@@ -91,6 +91,11 @@ class Matrix:
         L.check(L.lib().spmv_hip_mult(self._h, _ptr(x), _ptr(y)))
         return y
 
+    def set_row_map(self, d_row_map: int, keepalive=None) -> None:
+        """Row k of this (CSR scalar/vector) matrix writes y[row_map[k]]; device address of `rows` ints."""
+        L.check(L.lib().spmv_hip_set_row_map(self._h, d_row_map))
+        self._row_map_keepalive = keepalive
+
     def mult_dev(self, d_x: int, d_y: int, stream: int = 0) -> None:
         L.check(L.lib().spmv_hip_mult_dev(self._h, d_x, d_y, stream))
 
