@@ -1,0 +1,252 @@
+/*
+ * spmv_hip -- C driver for libspmv_hip with the command line, selection logic,
+ * measurement protocol and CSV schema of the reference driver
+ * (reference src/driver_spmv.c:112-347), so that it drops in behind spmv.run:
+ *
+ *     build/spmv_hip MODE LIST OUT.csv
+ *
+ * MODE is one of the reference's mode strings (driver_spmv.c:186-261) -- each
+ * selects the same storage format, now resident in HBM -- optionally suffixed
+ * with ":f32" for float storage/accumulation.  Per matrix of LIST the driver
+ *   1. estimates the memory need like enought_memory (driver_spmv.c:50-110;
+ *      .bin headers are read as binary here -- the reference parses them as text),
+ *   2. loads it (.mtx: spmv_hip_load_mtx; .bin: the reference's save_bin layout,
+ *      mtx.c:207-247) and insists on a square matrix (driver_spmv.c:176-179),
+ *   3. builds the format on the device,
+ *   4. fills x, y with the reference's interleaved rand() sequence and
+ *      normalises x (driver_spmv.c:267-273),
+ *   5. checks one product against the host COO loop (mult_mtx, mtx.c:270-276)
+ *      with the relative L2 error and the 1e-10 bar (driver_spmv.c:274-289,313),
+ *   6. runs the timed power loop with x, y resident in HBM (driver_spmv.c:292-305
+ *      -- only the product is timed, >= 10 iterations and > 2 s),
+ *   7. prints the table row and the CSV row (driver_spmv.c:311-316) with extra
+ *      columns appended: GB/s (algorithmic bytes), % of 8 TB/s, dtype, kernel variant.
+ * Library errors are printed and end the run with exit code 1, as the reference's
+ * helpers do (mtx.c:39-41, spmv.h:277-281).
+ */
+#include <ctype.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "spmv_hip.h"
+
+#define MAX_PATH_LEN 1024
+#define REFERENCE_BLOCK 4            /* _BLOCK of the reference's AVX2 build (spmv.h:20-22) */
+#define HBM_PEAK_GBS 8000.0
+
+static void die(const char *what)
+{
+    fprintf(stderr, "%s: %s\n", what, spmv_hip_last_error());
+    exit(1);
+}
+
+static double vec_norm(int n, const double *x)            /* driver_spmv.c:21-26 */
+{
+    double s = 0.0;
+    for (int i = 0; i < n; i++) s += x[i] * x[i];
+    return sqrt(s);
+}
+
+static unsigned long available_memory_kb(void)            /* driver_spmv.c:29-48 */
+{
+    FILE *f = fopen("/proc/meminfo", "r");
+    if (!f) return 0;
+    char line[256];
+    unsigned long kb = 0;
+    while (fgets(line, sizeof line, f)) {
+        if (strncmp(line, "MemAvailable:", 13) == 0) {
+            char *p = line + 13;
+            while (*p && !isdigit((unsigned char)*p)) p++;
+            kb = strtoul(p, NULL, 10);
+            break;
+        }
+    }
+    fclose(f);
+    return kb;
+}
+
+static int has_suffix(const char *s, const char *suffix)
+{
+    size_t a = strlen(s), b = strlen(suffix);
+    return a >= b && strcmp(s + a - b, suffix) == 0;
+}
+
+/* Sizes from the file header, and the reference's estimate 2*16*nnz + 8*(rows+cols) bytes in MB. */
+static int enough_memory(const char *path, long *rows, long *cols, long *nnz, unsigned long *need_mb)
+{
+    *rows = *cols = *nnz = 0;
+    FILE *f = fopen(path, "rb");
+    if (!f) { perror(path); return 0; }
+    if (has_suffix(path, ".bin")) {
+        int m, n; long nz;
+        if (fread(&m, sizeof m, 1, f) != 1 || fread(&n, sizeof n, 1, f) != 1 || fread(&nz, sizeof nz, 1, f) != 1) { fclose(f); return 0; }
+        *rows = m; *cols = n; *nnz = nz;
+    } else {
+        char line[1024];
+        int coordinate = 0;
+        if (fgets(line, sizeof line, f) && strstr(line, "coordinate")) coordinate = 1;
+        while (fgets(line, sizeof line, f)) if (line[0] != '%') break;
+        if (coordinate) sscanf(line, "%ld %ld %ld", rows, cols, nnz);
+        else { sscanf(line, "%ld %ld", rows, cols); *nnz = *rows * *cols; }
+    }
+    fclose(f);
+    unsigned long bytes = 2ul * (unsigned long)*nnz * 16ul + (unsigned long)(*rows + *cols) * 8ul;
+    *need_mb = bytes / (1024 * 1024);
+    unsigned long free_mb = available_memory_kb() / 1024;
+    return *need_mb < free_mb * 0.95;
+}
+
+/* load_bin with the layout save_bin writes (mtx.c:207-247): int rows, int cols, long nnz, then {int,int,double}. */
+static int load_bin(const char *path, int *rows, int *cols, int *nnz, struct mtx **coo)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) { fprintf(stderr, "Error opening file: %s\n", path); return 1; }
+    int m, n; long nz;
+    if (fread(&m, sizeof m, 1, f) != 1 || fread(&n, sizeof n, 1, f) != 1 || fread(&nz, sizeof nz, 1, f) != 1 ||
+        nz < 0 || nz > 0x7fffffffL) { fprintf(stderr, "Error reading file: %s\n", path); fclose(f); return 1; }
+    struct mtx *a = (struct mtx *)malloc(sizeof(struct mtx) * (size_t)(nz > 0 ? nz : 1));
+    if (!a) { fprintf(stderr, "Out of memory loading: %s\n", path); fclose(f); return 1; }
+    if (fread(a, sizeof(struct mtx), (size_t)nz, f) != (size_t)nz) { fprintf(stderr, "Error reading file: %s\n", path); free(a); fclose(f); return 1; }
+    fclose(f);
+    *rows = m; *cols = n; *nnz = (int)nz; *coo = a;
+    return 0;
+}
+
+/* COO -> plain CSR arrays on the host, for the creators that take CSR (the reference driver gets them from create_csr, driver_spmv.c:207,243) */
+static void coo_to_csr(int rows, int nnz, const struct mtx *coo, int **rp, int **cj, double **va)
+{
+    *rp = (int *)calloc((size_t)rows + 1, sizeof(int));
+    *cj = (int *)malloc(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
+    *va = (double *)malloc(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1));
+    for (int l = 0; l < nnz; l++) (*rp)[coo[l].i + 1]++;
+    for (int r = 0; r < rows; r++) (*rp)[r + 1] += (*rp)[r];
+    for (int l = 0; l < nnz; l++) { (*cj)[l] = coo[l].j; (*va)[l] = coo[l].a; }
+}
+
+/* MODE -> handle: the if/else chain of driver_spmv.c:186-261 */
+static spmv_hip_matrix *create_for_mode(const char *mode, int rows, int cols, int nnz, struct mtx *coo, int dtype)
+{
+    if (!strcmp(mode, "csr_base") || !strcmp(mode, "csr_autovec"))
+        return spmv_hip_create_csr(rows, cols, nnz, 1, coo, dtype, SPMV_HIP_CSR_SCALAR, 0);
+    if (!strcmp(mode, "csr_vec") || !strcmp(mode, "csr_highway"))
+        return spmv_hip_create_csr(rows, cols, nnz, REFERENCE_BLOCK, coo, dtype, SPMV_HIP_CSR_VECTOR, 0);
+    if (!strcmp(mode, "csr_merge")) return spmv_hip_create_csr_merge(rows, cols, nnz, coo, dtype, 0);
+    if (!strcmp(mode, "csr_bal")) return spmv_hip_create_csr_bal(rows, cols, nnz, coo, dtype, 0);
+    if (!strcmp(mode, "ell")) return spmv_hip_create_ell(rows, cols, nnz, coo, dtype, 0);
+    if (!strcmp(mode, "sellp_vec") || !strcmp(mode, "sellp_autovec") || !strcmp(mode, "sellp_highway") || !strcmp(mode, "sell")) {
+        int *rp, *cj; double *va;
+        spmv_hip_sort_coo(nnz, coo);                       /* create_csr's side effect (csr.c:167) */
+        coo_to_csr(rows, nnz, coo, &rp, &cj, &va);
+        spmv_hip_matrix *m = !strcmp(mode, "sell") ? spmv_hip_create_sell(rows, cols, nnz, rp, cj, va, dtype, 0, 0)
+                                                   : spmv_hip_create_sellp(rows, cols, nnz, rp, cj, va, dtype, 0);
+        free(rp); free(cj); free(va);
+        return m;
+    }
+    printf("Error: Unknown execution mode.\n");            /* driver_spmv.c:258-260 */
+    exit(-1);
+}
+
+int main(int argc, char *argv[])
+{
+    if (argc != 4) {
+        printf("Usage: spmv_hip [csr_base|csr_vec|csr_merge|csr_bal|sellp_vec|ell|sell][:f32] <mtx list> <output csv>\n");
+        exit(-1);
+    }
+    char mode[64];
+    snprintf(mode, sizeof mode, "%s", argv[1]);
+    int dtype = SPMV_HIP_F64;
+    char *colon = strchr(mode, ':');
+    if (colon) {
+        if (!strcmp(colon, ":f32")) dtype = SPMV_HIP_F32;
+        else if (strcmp(colon, ":f64")) { printf("Error: Unknown execution mode.\n"); exit(-1); }
+        *colon = 0;
+    }
+    const int vbytes = dtype == SPMV_HIP_F32 ? 4 : 8;
+    FILE *infd = fopen(argv[2], "r");
+    if (!infd) { perror("Error openning file input for matrix list.\n"); exit(-1); }
+    FILE *outfd = fopen(argv[3], "w");
+    if (!outfd) { perror(argv[3]); exit(-1); }
+    if (spmv_hip_init(0)) die("spmv_hip_init");
+
+    fprintf(outfd, "Format;File;Rows;Columns;NNZ;GFlops;Time(s);GB/s;PctHBMPeak;Dtype;Variant\n");
+    printf("\n  Format: %s   dtype: %s   list: %s   csv: %s\n\n", mode, dtype == SPMV_HIP_F32 ? "f32" : "f64", argv[2], argv[3]);
+    printf("  %-30s %10s %10s %11s | %10s %11s %9s | %8s %6s | %11s  %s\n", "Matrix", "ROWS", "COLUMNS", "NNZ", "GFlops",
+           "T(s)", "Mem (Mb)", "GB/s", "%HBM", "ERROR", "Test");
+
+    char line[MAX_PATH_LEN];
+    while (fgets(line, sizeof line, infd)) {
+        line[strcspn(line, "\r\n")] = 0;
+        if (!line[0]) continue;
+        const char *slash = strrchr(line, '/');
+        const char *name = slash ? slash + 1 : line;
+        long hrows, hcols, hnnz;
+        unsigned long need_mb;
+        if (!enough_memory(line, &hrows, &hcols, &hnnz, &need_mb)) {      /* driver_spmv.c:332-337 */
+            printf("  %-30s %10ld %10ld %11ld | %10.4f %11.4e %9lu | %8.1f %6.1f | %11.4e  ---\n", name, hrows, hcols, hnnz,
+                   0.0, 0.0, need_mb, 0.0, 0.0, 0.0);
+            fprintf(outfd, "%s;%s;%ld;%ld;%ld;%.5e;%.5e;%.5e;%.2f;%s;%d\n", argv[1], name, hrows, hcols, hnnz, 0.0, 0.0, 0.0, 0.0,
+                    dtype == SPMV_HIP_F32 ? "f32" : "f64", 0);
+            continue;
+        }
+        int rows, columns, nnz;
+        struct mtx *coo;
+        if (has_suffix(line, ".bin")) { if (load_bin(line, &rows, &columns, &nnz, &coo)) exit(1); }
+        else if (has_suffix(line, ".mtx")) { if (spmv_hip_load_mtx(line, &rows, &columns, &nnz, &coo)) die("load_mtx"); }
+        else { printf("Unkown file extension\n"); return 1; }
+        if (rows != columns) { printf("Matrix is not square\n"); return 1; }
+
+        spmv_hip_matrix *m = create_for_mode(mode, rows, columns, nnz, coo, dtype);
+        if (!m) die("create");
+        if (spmv_hip_analyze(m, 3)) die("analyze");
+
+        double *x = (double *)malloc(sizeof(double) * (size_t)columns);
+        double *y = (double *)malloc(sizeof(double) * ((size_t)rows + 64));
+        double *y_ref = (double *)malloc(sizeof(double) * (size_t)rows);
+        for (int i = 0; i < columns; i++) {                               /* driver_spmv.c:267-270 */
+            x[i] = ((double)rand()) / RAND_MAX;
+            y[i] = ((double)rand()) / RAND_MAX;
+        }
+        double norm = vec_norm(columns, x);
+        for (int i = 0; i < columns; i++) x[i] /= norm;
+        if (dtype == SPMV_HIP_F32)                     /* compare against what the device will see */
+            for (int i = 0; i < columns; i++) x[i] = (double)(float)x[i];
+        for (int i = 0; i < rows; i++) y_ref[i] = 0.0;                    /* mult_mtx, mtx.c:270-276 */
+        for (int k = 0; k < nnz; k++) y_ref[coo[k].i] += x[coo[k].j] * coo[k].a;
+
+        if (spmv_hip_mult(m, x, y)) die("mult");
+        double error = 0.0, nrm = 0.0;                                    /* driver_spmv.c:278-289 */
+        for (int i = 0; i < rows; i++) {
+            nrm += y_ref[i] * y_ref[i];
+            double d = fabs(y[i] - y_ref[i]);
+            error += d * d;
+        }
+        error = nrm != 0.0 ? sqrt(error) / sqrt(nrm) : sqrt(error);
+
+        int it = 0;
+        double time_spmv = 0.0;
+        const char *ms = getenv("SPMV_MIN_SECONDS");                      /* default: the reference's 2 s (:303) */
+        if (spmv_hip_bench(m, 10, ms ? atof(ms) : 2.0, x, &it, &time_spmv)) die("bench");
+        double gflops = 2.0 * nnz * it / time_spmv / 1e9;                 /* driver_spmv.c:307-308 */
+        double ftime = time_spmv / it;
+        double bytes = (double)nnz * (vbytes + 4) + (double)rows * (4 + vbytes) + (double)columns * vbytes;
+        double gbs = bytes / ftime / 1e9;
+        spmv_hip_info info;
+        spmv_hip_get_info(m, &info);
+        const double bar = dtype == SPMV_HIP_F32 ? 1e-5 : 1e-10;          /* driver_spmv.c:313 (fp64) */
+        printf("  %-30s %10d %10d %11d | %10.4f %11.4e %9lu | %8.1f %6.1f | %11.4e  %s\n", name, rows, columns, nnz, gflops,
+               ftime, need_mb, gbs, 100.0 * gbs / HBM_PEAK_GBS, error, error < bar ? "OK" : "ERR");
+        fprintf(outfd, "%s;%s;%d;%d;%d;%.5e;%.5e;%.5e;%.2f;%s;%d\n", argv[1], name, rows, columns, nnz, gflops, ftime, gbs,
+                100.0 * gbs / HBM_PEAK_GBS, dtype == SPMV_HIP_F32 ? "f32" : "f64", info.variant);
+        fflush(outfd);
+
+        free(x); free(y); free(y_ref);
+        spmv_hip_free_coo(coo);
+        spmv_hip_free(m);
+    }
+    printf("\n");
+    fclose(infd);
+    fclose(outfd);
+    return 0;
+}

@@ -1,0 +1,80 @@
+"""The C driver build/spmv_hip: command line, CSV schema and OK/ERR check of the
+reference driver (reference src/driver_spmv.c:112-347) on top of libspmv_hip."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from spmv_amd import generators as G
+from tests.util import ROOT
+
+DRIVER = os.path.join(ROOT, "spmv_amd", "csrc", "build", "spmv_hip")
+REF_HEADER = "Format;File;Rows;Columns;NNZ;GFlops;Time(s)"          # driver_spmv.c:139
+
+
+def test_usage_and_unknown_mode_exit_like_reference(tmp_path):
+    assert os.path.exists(DRIVER), "build the driver with make -C spmv_amd/csrc"
+    p = subprocess.run([DRIVER], capture_output=True, text=True)
+    assert p.returncode == 255 and "Usage" in p.stdout                # exit(-1), driver_spmv.c:126-129
+    p = subprocess.run([DRIVER, "sell", str(tmp_path / "nolist.txt"), str(tmp_path / "o.csv")], capture_output=True, text=True)
+    assert p.returncode == 255                                        # list missing: exit(-1), :134-137
+
+
+def _write_bin(path, rows, cols, coo):
+    """Layout of the reference's save_bin (mtx.c:207-247)."""
+    with open(path, "wb") as f:
+        f.write(struct.pack("iiq", rows, cols, len(coo)))
+        f.write(coo.tobytes())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["csr_base", "csr_vec", "csr_merge", "csr_bal", "sellp_vec", "ell", "sell", "sell:f32"])
+def test_driver_runs_every_mode(tmp_path, mode):
+    mats = []
+    for name, gen in (("lap2d_40", G.laplacian2d(40)), ("stencil_9", G.stencil27(9))):
+        rows, cols, rp, cj, va = gen
+        coo = G.csr_to_coo_numpy(rows, rp, cj, va)
+        path = str(tmp_path / f"{name}.mtx")
+        G.write_mtx(path, rows, cols, coo)
+        mats.append((path, rows, len(coo)))
+    rows, cols, rp, cj, va = G.band(300, 4)
+    coo = G.csr_to_coo_numpy(rows, rp, cj, va)
+    bpath = str(tmp_path / "band_300.bin")
+    _write_bin(bpath, rows, cols, coo)
+    mats.append((bpath, rows, len(coo)))
+    lst = str(tmp_path / "list.txt")
+    open(lst, "w").write("\n".join(m[0] for m in mats) + "\n")
+    out = str(tmp_path / "out.csv")
+    env = dict(os.environ, SPMV_MIN_SECONDS="0.05")      # the reference's 2 s rule, shortened for the test
+    p = subprocess.run([DRIVER, mode, lst, out], capture_output=True, text=True, timeout=110, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = open(out).read().strip().split("\n")
+    assert lines[0].startswith(REF_HEADER)
+    assert len(lines) == 1 + len(mats)
+    for line, (path, rows, nnz) in zip(lines[1:], mats):
+        f = line.split(";")
+        assert f[0] == mode and f[1] == os.path.basename(path)
+        assert int(f[2]) == rows and int(f[3]) == rows and int(f[4]) == nnz
+        assert float(f[5]) > 0 and float(f[6]) > 0
+    verdicts = [l.split()[-1] for l in p.stdout.splitlines() if l.strip() and l.split()[-1] in ("OK", "ERR", "---")]
+    assert verdicts == ["OK"] * len(mats), p.stdout          # driver_spmv.c:313-314
+
+
+@pytest.mark.gpu
+def test_driver_rejects_non_square_and_unknown_mode(tmp_path):
+    from spmv_amd.matrix import make_coo
+    coo = make_coo([0, 1], [0, 2], [1.0, 2.0])
+    path = str(tmp_path / "rect.mtx")
+    G.write_mtx(path, 2, 3, coo)
+    lst = str(tmp_path / "list.txt")
+    open(lst, "w").write(path + "\n")
+    p = subprocess.run([DRIVER, "csr_base", lst, str(tmp_path / "o.csv")], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 1 and "Matrix is not square" in p.stdout        # driver_spmv.c:176-179
+    rows, cols, rp, cj, va = G.laplacian2d(5)
+    sq = str(tmp_path / "sq.mtx")
+    G.write_mtx(sq, rows, cols, G.csr_to_coo_numpy(rows, rp, cj, va))
+    open(lst, "w").write(sq + "\n")
+    p = subprocess.run([DRIVER, "nonsense", lst, str(tmp_path / "o.csv")], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 255 and "Unknown execution mode" in p.stdout    # driver_spmv.c:258-260
