@@ -113,10 +113,10 @@ static void release_csr(spmv_hip_matrix *m)
 static int normalize_tile_param(int64_t p, int dflt, int *out)
 {
     int v = p == 0 ? dflt : (int)p;
-    const int ok[] = {4, 7, 8, 12, 16};
+    const int ok[] = {256, 512, 1024, 2048};     // 64 lanes x {4, 8, 16, 32} items
     for (int k : ok)
-        if (v == k * kBlock) { *out = v; return 0; }
-    set_error("tile size %d must be 256 x {4,7,8,12,16}", v);
+        if (v == k) { *out = v; return 0; }
+    set_error("tile size %d must be one of 256, 512, 1024, 2048", v);
     return 1;
 }
 
@@ -133,10 +133,10 @@ static int finish_from_device_csr(spmv_hip_matrix *m, int64_t p0, int64_t p1, bo
         return 0;
     }
     case SPMV_HIP_CSR_MERGE:
-        if (normalize_tile_param(p0, 7 * kBlock, &m->items_per_tile)) return 1;
+        if (normalize_tile_param(p0, 512, &m->items_per_tile)) return 1;
         return build_merge_tiles(m, st);
     case SPMV_HIP_CSR_BAL:
-        if (normalize_tile_param(p0, 7 * kBlock, &m->items_per_tile)) return 1;
+        if (normalize_tile_param(p0, 512, &m->items_per_tile)) return 1;
         return build_bal_tiles(m, st);
     case SPMV_HIP_SELL:
     case SPMV_HIP_SELLP:
@@ -413,18 +413,20 @@ int spmv_hip_analyze(spmv_hip_matrix *m, int reps)
     if (reps < 1) reps = 3;
     int cand[32];
     const int n = variant_candidates(m, cand, 32);
-    if (n <= 1 || m->rows == 0) return 0;
+    if (n <= 1 || m->rows == 0 || m->d_row_map) return 0;   // row-mapped handles write outside d_y
     if (ensure_vectors(m)) return 1;
     const size_t es = dtype_size(m->dtype);
     SPMV_HIP_TRY(hipMemset(m->d_x, 0, (size_t)std::max(m->columns, 1) * es), return 1);
     hipEvent_t e0, e1;
     SPMV_HIP_TRY(hipEventCreate(&e0), return 1);
     SPMV_HIP_TRY(hipEventCreate(&e1), return 1);
-    const int keep = m->variant;
+    // the knob under trial: lanes per row for the vector CSR kernel, the kernel variant otherwise
+    int &knob = m->format == SPMV_HIP_CSR_VECTOR ? m->lanes_per_row : m->variant;
+    const int keep = knob;
     int best = keep, rc = 0;
     float best_ms = 0;
     for (int i = 0; i < n && !rc; i++) {
-        m->variant = cand[i];
+        knob = cand[i];
         if (launch_mult(m, m->d_x, m->d_y, nullptr)) { rc = 1; break; }          // warm-up
         float total = 0;
         for (int r = 0; r < reps; r++) {
@@ -438,7 +440,7 @@ int spmv_hip_analyze(spmv_hip_matrix *m, int reps)
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    m->variant = rc ? keep : best;
+    knob = rc ? keep : best;
     if (rc && !g_error[0]) set_error("analyze: timing a kernel variant failed");
     return rc;
 }

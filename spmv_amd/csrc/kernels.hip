@@ -241,116 +241,108 @@ __global__ __launch_bounds__(kBlock) void sliced_any_kernel(int rows, int height
 }
 
 // ------------------------------------------------ merge-path / balanced tiles --
-// One workgroup per tile.  A tile is the path segment between two precomputed
-// coordinates (a = position in the row-end list, b = position in the non-zero
-// list): tile_coord[2t..2t+1] -> tile_coord[2t+2..2t+3].
+// A tile is the path segment between two precomputed coordinates (a = position
+// in the row-end list, b = position in the non-zero list):
+// tile_coord[2t..2t+1] -> tile_coord[2t+2..2t+3].
 //   merge-path CSR: row-end list = row_ptr+1, tiles are equal shares of the
-//     rows+nnz merge path (reference csr_merge.c:18-30).
+//     rows+nnz merge path; the coordinates come from the reference's 2-D
+//     diagonal search (csr_merge.c:18-30, 62-85) done once at create time,
+//     where the reference freezes its thread count too (csr_merge.c:93).
 //   balanced CSR:   row-end list = ends of the non-empty rows, tiles are equal
 //     shares of the non-zeros (reference csr_bal.c:83-85); row_index maps a
 //     list position back to its row.
-// Phase 1 stages the tile's row ends and its products val*x[col] in LDS with
-// fully coalesced loads.  Phase 2 gives every thread an equal share of the
-// tile's path (2-D diagonal search in LDS, reference csr_merge.c:62-85) which
-// it consumes serially (csr_merge.c:32-46).  A row finished by a thread that
-// did not start it needs the partial sums of the threads before it: segmented
-// scan over the threads' trailing partial sums.  The tile's own trailing
-// partial goes to (row_carry, val_carry) and is added by tile_fixup_kernel in
-// tile order (csr_merge.c:48-58, csr_bal.c:33-37).
+// Phase 1 stages the tile's row ends (the row pointers) and its products
+// val*x[col] in LDS with fully coalesced loads.  Phase 2 sums whole rows out of
+// LDS (csr_merge.c:32-41).  The tile's trailing partial row goes to
+// (row_carry, val_carry) and is added by tile_fixup_kernel in tile order
+// (csr_merge.c:43-58, csr_bal.c:33-37).
+//
+// One 64-lane workgroup per tile of 64*IPL items, so waves never wait for each
+// other.  Phase 2 gives every row that ends in the tile (plus the trailing
+// partial row) to one lane, which adds the row's products in ascending order;
+// rows longer than kLongRow entries are summed by the whole wave instead.  A
+// tile that lies inside a single row reduces its registers directly.
+constexpr int kLongRow = 48;
 
-template <typename T> struct SegPair { int flag; T value; };
-
-template <typename T>
-__device__ __forceinline__ SegPair<T> seg_combine(SegPair<T> left, SegPair<T> right)
+template <typename T, int IPL>
+__global__ __launch_bounds__(kWave) void wave_tile_kernel(int list_len, const int *__restrict__ row_end_list,
+                                                          const int *__restrict__ row_index,
+                                                          const int *__restrict__ tile_coord,
+                                                          const int *__restrict__ col,
+                                                          const T *__restrict__ val,
+                                                          const T *__restrict__ x, T *__restrict__ y,
+                                                          int *__restrict__ row_carry, T *__restrict__ val_carry)
 {
-    SegPair<T> r;
-    r.flag = left.flag | right.flag;
-    r.value = right.flag ? right.value : left.value + right.value;
-    return r;
-}
-
-template <typename T, int IPT>
-__global__ __launch_bounds__(kBlock) void tile_kernel(int list_len, const int *__restrict__ row_end_list,
-                                                      const int *__restrict__ row_index,
-                                                      const int *__restrict__ tile_coord,
-                                                      const int *__restrict__ col,
-                                                      const T *__restrict__ val,
-                                                      const T *__restrict__ x, T *__restrict__ y,
-                                                      int *__restrict__ row_carry, T *__restrict__ val_carry)
-{
-    constexpr int kCap = kBlock * IPT;       // most non-zeros (and most rows) of a tile
+    constexpr int kCap = kWave * IPL;
     __shared__ T prod[kCap];
     __shared__ int rend[kCap];
-    __shared__ int wave_flag[kBlock / kWave];
-    __shared__ T wave_val[kBlock / kWave];
-
     const int t = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
-    const int tid = threadIdx.x;
+    const int lane = threadIdx.x;
     const int a0 = tile_coord[2 * t], b0 = tile_coord[2 * t + 1];
     const int a1 = tile_coord[2 * t + 2], b1 = tile_coord[2 * t + 3];
-    const int nr = a1 - a0, nz = b1 - b0, total = nr + nz;
+    const int nr = a1 - a0, nz = b1 - b0;
 
-    // phase 1: coalesced staging
+    // phase 1: IPL coalesced (column, value) loads per lane, then the gathers, all in flight together
+    T pp[IPL];
+    if (nz > 0) {
+        int cc[IPL];
+        T vv[IPL], xx[IPL];
 #pragma unroll
-    for (int i = 0; i < IPT; i++) {
-        int k = tid + i * kBlock;
-        if (k < nz) prod[k] = val[b0 + k] * x[col[b0 + k]];
+        for (int i = 0; i < IPL; i++) cc[i] = col[b0 + min(lane + i * kWave, nz - 1)];
+#pragma unroll
+        for (int i = 0; i < IPL; i++) vv[i] = val[b0 + min(lane + i * kWave, nz - 1)];
+#pragma unroll
+        for (int i = 0; i < IPL; i++) xx[i] = x[cc[i]];
+#pragma unroll
+        for (int i = 0; i < IPL; i++) pp[i] = lane + i * kWave < nz ? vv[i] * xx[i] : (T)0;
+    } else {
+#pragma unroll
+        for (int i = 0; i < IPL; i++) pp[i] = 0;
     }
-    for (int k = tid; k < nr; k += kBlock) rend[k] = row_end_list[a0 + k] - b0;
+
+    if (nr == 0) {                               // the tile is a piece of one row
+        T s = 0;
+#pragma unroll
+        for (int i = 0; i < IPL; i++) s += pp[i];
+        s = group_sum<kWave>(s);
+        if (lane == 0) { row_carry[t] = a1; val_carry[t] = s; }
+        return;
+    }
+
+#pragma unroll
+    for (int i = 0; i < IPL; i++) {
+        int k = lane + i * kWave;
+        if (k < nz) prod[k] = pp[i];
+        if (k < nr) rend[k] = row_end_list[a0 + k] - b0;
+    }
     __syncthreads();
 
-    // phase 2: this thread's share of the tile's path
-    const int per_thread = (total + kBlock - 1) / kBlock;
-    int d = min(tid * per_thread, total);
-    const int d_end = min(d + per_thread, total);
-    int lo = max(d - nz, 0), hi = min(d, nr);
-    while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        if (rend[mid] <= d - mid - 1) lo = mid + 1; else hi = mid;
-    }
-    int a = lo, b = d - lo;
-
-    T run = 0, first_val = 0;
-    int first_row = -1;
-    for (; d < d_end; d++) {
-        int re = a < nr ? rend[a] : 0x7fffffff;
-        if (b < re) {
-            run += prod[b];
-            b++;
-        } else {
-            if (first_row < 0) { first_row = a; first_val = run; }
-            else y[row_index ? row_index[a0 + a] : a0 + a] = run;
-            run = 0;
-            a++;
+    for (int base = 0; base <= nr; base += kWave) {
+        const int rr = base + lane;              // row slot: rr < nr ends here, rr == nr is the trailing partial row
+        const bool valid = rr <= nr;
+        int start = 0, end = 0;
+        if (valid) {
+            start = rr == 0 ? 0 : rend[rr - 1];
+            end = rr < nr ? rend[rr] : nz;
         }
-    }
-
-    // segmented inclusive scan of (finished a row?, trailing partial) over the workgroup
-    SegPair<T> p{first_row >= 0 ? 1 : 0, run};
-    const int lane = tid & (kWave - 1), wave = tid / kWave;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        SegPair<T> o;
-        o.flag = __shfl_up(p.flag, off, kWave);
-        o.value = __shfl_up(p.value, off, kWave);
-        if (lane >= off) p = seg_combine(o, p);
-    }
-    if (lane == kWave - 1) { wave_flag[wave] = p.flag; wave_val[wave] = p.value; }
-    // exclusive value inside the wave
-    T carry_in = __shfl_up(p.value, 1, kWave);
-    int carry_flag = __shfl_up(p.flag, 1, kWave);
-    if (lane == 0) { carry_in = 0; carry_flag = 0; }
-    __syncthreads();
-    SegPair<T> before{0, 0};                 // everything in the waves before this one
-    for (int w = 0; w < wave; w++) before = seg_combine(before, SegPair<T>{wave_flag[w], wave_val[w]});
-    if (!carry_flag) carry_in += before.value;
-
-    if (first_row >= 0) y[row_index ? row_index[a0 + first_row] : a0 + first_row] = first_val + carry_in;
-
-    if (tid == kBlock - 1) {
-        SegPair<T> all = seg_combine(before, p);
-        row_carry[t] = a1;
-        val_carry[t] = all.value;
+        const int len = end - start;
+        T s = 0;
+        if (len <= kLongRow)
+            for (int k = start; k < end; k++) s += prod[k];
+        unsigned long long longrows = __ballot(len > kLongRow);
+        while (longrows) {
+            const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(longrows));
+            longrows &= longrows - 1;
+            const int ls = __builtin_amdgcn_readlane(start, src), le = __builtin_amdgcn_readlane(end, src);
+            T part = 0;
+            for (int k = ls + lane; k < le; k += kWave) part += prod[k];
+            part = group_sum<kWave>(part);
+            if (lane == src) s = part;
+        }
+        if (valid) {
+            if (rr < nr) y[row_index ? row_index[a0 + rr] : a0 + rr] = s;
+            else { row_carry[t] = a1; val_carry[t] = s; }
+        }
     }
 }
 
@@ -454,6 +446,10 @@ int variant_candidates(const spmv_hip_matrix *m, int *out, int max_out)
     if (sliced64) {
         for (int v : kSlicedVariants)
             if (n < max_out) out[n++] = v;
+    } else if (m->format == SPMV_HIP_CSR_VECTOR) {
+        // for the vector CSR kernel the "variant" tried by analyze is the lanes-per-row group size
+        for (int g = 2; g <= 64; g *= 2)
+            if (n < max_out) out[n++] = g;
     } else if (n < max_out) {
         out[n++] = 0;
     }
@@ -520,23 +516,22 @@ template <typename T> static int launch_tiles(const spmv_hip_matrix *m, const T 
         return 0;
     }
     // merge tiles hold items_per_tile path items; balanced tiles hold that many non-zeros
-    const int ipt = m->items_per_tile / kBlock;
-#define SPMV_TILE_CASE(I)                                                                            \
-    case I:                                                                                          \
-        hipLaunchKernelGGL((tile_kernel<T, I>), dim3(m->ntiles), dim3(kBlock), 0, st, list_len, list, \
-                           index, m->d_tile_coord, m->d_col, va, x, y, m->d_row_carry, vc);          \
+    if (m->variant != 0) { set_error("tile kernel: unknown kernel variant %d", m->variant); return 1; }
+#define SPMV_WTILE_CASE(I)                                                                               \
+    case I:                                                                                              \
+        hipLaunchKernelGGL((wave_tile_kernel<T, I>), dim3(m->ntiles), dim3(kWave), 0, st, list_len, list, \
+                           index, m->d_tile_coord, m->d_col, va, x, y, m->d_row_carry, vc);              \
         break;
-    switch (ipt) {
-        SPMV_TILE_CASE(4)
-        SPMV_TILE_CASE(7)
-        SPMV_TILE_CASE(8)
-        SPMV_TILE_CASE(12)
-        SPMV_TILE_CASE(16)
+    switch (m->items_per_tile % kWave ? 0 : m->items_per_tile / kWave) {
+        SPMV_WTILE_CASE(4)
+        SPMV_WTILE_CASE(8)
+        SPMV_WTILE_CASE(16)
+        SPMV_WTILE_CASE(32)
     default:
-        set_error("tile kernel: items_per_tile %d must be 256 x {4,7,8,12,16}", m->items_per_tile);
+        set_error("tile kernel: items_per_tile %d must be 64 x {4,8,16,32}", m->items_per_tile);
         return 1;
     }
-#undef SPMV_TILE_CASE
+#undef SPMV_WTILE_CASE
     hipLaunchKernelGGL((tile_fixup_kernel<T>), dim3(cdiv(m->ntiles, kBlock)), dim3(kBlock), 0, st, m->ntiles,
                        list_len, index, m->d_row_carry, vc, y);
     return 0;

@@ -106,7 +106,7 @@ def test_c3_rmat_scale22_merge_and_balanced(orc):
     y_ref = _mult(scalar, x, rows)
     want = orc.mult_csr_base(rp.cpu().numpy(), cj.cpu().numpy(), va.cpu().numpy(), x.cpu().numpy())
     assert y_ref.cpu().numpy().tobytes() == want.tobytes()
-    for fmt, p0 in [(S.CSR_MERGE, 0), (S.CSR_MERGE, 16 * 256), (S.CSR_BAL, 0), (S.CSR_BAL, 4 * 256), (S.CSR_VECTOR, 0)]:
+    for fmt, p0 in [(S.CSR_MERGE, 0), (S.CSR_MERGE, 2048), (S.CSR_BAL, 0), (S.CSR_BAL, 256), (S.CSR_VECTOR, 0)]:
         m = _dev_matrix(fmt, rows, cols, rp, cj, va, p0)
         y = _mult(m, x, rows)
         assert not torch.isnan(y).any()

@@ -72,10 +72,11 @@ def test_csr_vector(orc, g, lanes):
     assert rel(orc, y, g["y_csr_vec"]) <= TOL_REASSOC
 
 
-@pytest.mark.parametrize("items", [0, 4 * 256, 16 * 256])
+@pytest.mark.parametrize("items", [0, 256, 2048])
 def test_csr_merge(orc, g, items):
     rows = int(g["rows"])
     m = Matrix.csr_merge(rows, int(g["cols"]), coo_of(g), S.F64, items)
+    assert m.info.items_per_tile == (items or 512)
     info = m.info
     rp = g["csr1_row_ptr"]
     nnz = len(g["csr1_col"])
@@ -89,7 +90,7 @@ def test_csr_merge(orc, g, items):
     assert rel(orc, y, g["y_csr_merge_t8"]) <= TOL_REASSOC
 
 
-@pytest.mark.parametrize("chunk", [0, 4 * 256])
+@pytest.mark.parametrize("chunk", [0, 256, 1024])
 def test_csr_bal_handles_empty_rows_too(orc, g, chunk):
     m = Matrix.csr_bal(int(g["rows"]), int(g["cols"]), coo_of(g), S.F64, chunk)
     y = m.mult(g["x"])
@@ -97,6 +98,13 @@ def test_csr_bal_handles_empty_rows_too(orc, g, chunk):
     assert rel(orc, y, g["y_csr_base"]) <= TOL_REASSOC
     if "y_csr_bal_t8" in g:
         assert rel(orc, y, g["y_csr_bal_t8"]) <= TOL_REASSOC
+
+
+def test_csr_vector_analyze_picks_a_group_size(orc, g):
+    m = Matrix.csr(int(g["rows"]), int(g["cols"]), coo_of(g), 1, S.F64, S.CSR_VECTOR)
+    m.analyze(2)
+    assert m.info.lanes_per_row in (2, 4, 8, 16, 32, 64)
+    assert rel(orc, m.mult(g["x"]), g["y_csr_base"]) <= TOL_REASSOC
 
 
 @pytest.mark.parametrize("sigma", CS.SELL_SIGMAS)
