@@ -38,7 +38,7 @@ def parse_args():
     ap.add_argument("--format", default="sell", choices=["sell", "sellp", "ell", "csr_scalar", "csr_vector",
                                                            "csr_merge", "csr_bal"])
     ap.add_argument("--matrix", default="stencil27", choices=["stencil27", "laplacian2d", "rmat"])
-    ap.add_argument("--n", type=int, default=0, help="grid edge (stencil27: 252, laplacian2d: 1000) or R-MAT scale")
+    ap.add_argument("--size", dest="n", type=int, default=0, help="grid edge (stencil27: 252, laplacian2d: 1000) or R-MAT scale")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--sigma", type=int, default=1024)
     ap.add_argument("--p0", type=int, default=0, help="format parameter (lanes per row / tile size / slice height)")
@@ -127,11 +127,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    S.lib().spmv_hip_init(local_rank)
+    # SPMV_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+    # (ranks share devices, halo staged through the host); the driver's runs use nccl = RCCL.
+    backend = os.environ.get("SPMV_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    S.lib().spmv_hip_init(dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     dtype = S.F64 if args.dtype == "f64" else S.F32
     tdtype = torch.float64 if dtype == S.F64 else torch.float32

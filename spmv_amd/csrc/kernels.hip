@@ -11,8 +11,11 @@
 //     entry -- the order of mult_csr_base (reference csr.c:4-13); bit-identical
 //     to it.
 //   csr_vector: G interleaved partial sums per row + butterfly.
-//   tile (merge-path / balanced): product rounded, then per-thread runs,
-//     segmented scan over threads, tile carries added in tile order.
+//   sliced wide variants: 2 (fp64) / 4 (fp32) interleaved partial sums per row.
+//   tile (merge-path / balanced): product rounded, then each row's products
+//     added in ascending order by one lane (rows longer than kLongRow: 64
+//     interleaved partial sums + butterfly); a row cut by tile boundaries gets
+//     its pieces added in tile order.
 
 #include "internal.h"
 
@@ -327,8 +330,17 @@ __global__ __launch_bounds__(kWave) void wave_tile_kernel(int list_len, const in
         }
         const int len = end - start;
         T s = 0;
-        if (len <= kLongRow)
-            for (int k = start; k < end; k++) s += prod[k];
+        if (len <= kLongRow) {
+            int k = start;
+            for (; k + 8 <= end; k += 8) {           // 8 LDS reads in flight, added in ascending order
+                T p[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) p[u] = prod[k + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) s += p[u];
+            }
+            for (; k < end; k++) s += prod[k];
+        }
         unsigned long long longrows = __ballot(len > kLongRow);
         while (longrows) {
             const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(longrows));
@@ -516,10 +528,9 @@ template <typename T> static int launch_tiles(const spmv_hip_matrix *m, const T 
         return 0;
     }
     // merge tiles hold items_per_tile path items; balanced tiles hold that many non-zeros
-    if (m->variant != 0) { set_error("tile kernel: unknown kernel variant %d", m->variant); return 1; }
 #define SPMV_WTILE_CASE(I)                                                                               \
     case I:                                                                                              \
-        hipLaunchKernelGGL((wave_tile_kernel<T, I>), dim3(m->ntiles), dim3(kWave), 0, st, list_len, list, \
+        hipLaunchKernelGGL((wave_tile_kernel<T, I>), dim3(m->ntiles), dim3(kWave), 0, st, list_len, list,   \
                            index, m->d_tile_coord, m->d_col, va, x, y, m->d_row_carry, vc);              \
         break;
     switch (m->items_per_tile % kWave ? 0 : m->items_per_tile / kWave) {

@@ -55,8 +55,12 @@ def main():
         pp0 = p0 or (64 if fmt == S.SELL else 0)
         m = Matrix.from_device_csr(fmt, rows, cols, nnz, rp.data_ptr(), cj.data_ptr(), va.data_ptr(), dtype, pp0,
                                    args.sigma if fmt == S.SELL else 0, st)
-        for var in [int(v) for v in args.variants.split(",")]:
-            m.set_option("variant", var)
+        for var in [v if v == "auto" else int(v) for v in args.variants.split(",")]:
+            if var == "auto":
+                m.analyze(3)
+                var = m.info.lanes_per_row if fmt == S.CSR_VECTOR else m.info.variant
+            else:
+                m.set_option("variant", var)
             for _ in range(3):
                 m.mult_dev(x.data_ptr(), y.data_ptr(), st)
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
