@@ -181,7 +181,9 @@ int spmv_hip_set_option(spmv_hip_matrix *m, const char *name, int64_t value);
 /* sellcs_analyze_matrix (sell.c:30, sellcs_analyzer.c:46-120) re-thought for the
  * GPU: times every kernel variant of the handle's format `reps` times on a
  * zero vector and keeps the fastest.  Variant 0 of the sliced formats keeps
- * mult_csr_base's summation order (bit-identical y); the others reassociate. */
+ * mult_csr_base's summation order (bit-identical y); the others reassociate.
+ * All CSR_SCALAR variants (LDS chunk sizes) give the same bits.  For CSR_VECTOR
+ * the trial covers lanes per row x rows walked side by side per lane group. */
 int spmv_hip_analyze(spmv_hip_matrix *m, int reps);
 
 /* ---- introspection for layout-parity tests ---------------------------------- */

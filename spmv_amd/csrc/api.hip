@@ -420,13 +420,17 @@ int spmv_hip_analyze(spmv_hip_matrix *m, int reps)
     hipEvent_t e0, e1;
     SPMV_HIP_TRY(hipEventCreate(&e0), return 1);
     SPMV_HIP_TRY(hipEventCreate(&e1), return 1);
-    // the knob under trial: lanes per row for the vector CSR kernel, the kernel variant otherwise
-    int &knob = m->format == SPMV_HIP_CSR_VECTOR ? m->lanes_per_row : m->variant;
-    const int keep = knob;
+    // a candidate is a kernel variant; for the vector CSR kernel it also carries the lanes per row (low byte)
+    const bool vec = m->format == SPMV_HIP_CSR_VECTOR;
+    auto apply = [&](int c) {
+        if (vec) { m->lanes_per_row = c & 255; m->variant = c >> 8; }
+        else m->variant = c;
+    };
+    const int keep = vec ? m->lanes_per_row + 256 * m->variant : m->variant;
     int best = keep, rc = 0;
     float best_ms = 0;
     for (int i = 0; i < n && !rc; i++) {
-        knob = cand[i];
+        apply(cand[i]);
         if (launch_mult(m, m->d_x, m->d_y, nullptr)) { rc = 1; break; }          // warm-up
         float total = 0;
         for (int r = 0; r < reps; r++) {
@@ -440,7 +444,7 @@ int spmv_hip_analyze(spmv_hip_matrix *m, int reps)
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    knob = rc ? keep : best;
+    apply(rc ? keep : best);
     if (rc && !g_error[0]) set_error("analyze: timing a kernel variant failed");
     return rc;
 }

@@ -83,26 +83,123 @@ __global__ __launch_bounds__(kBlock) void csr_scalar_kernel(int rows, const int 
     y[row_map ? row_map[row] : row] = s;
 }
 
+// Lane per row with the matrix stream staged through LDS.  A 64-lane workgroup
+// owns 64 consecutive rows, i.e. one contiguous run of the column and value
+// arrays; it walks that run in chunks of 64*IPL entries.  Per chunk: coalesced
+// (column, value) loads, the x gathers, then (x, value) pairs parked in LDS,
+// from where every lane adds the part of its own row that lies in the chunk --
+// one fma per entry in ascending position, the accumulator carried from chunk
+// to chunk.  Same rounding sequence as csr_scalar_kernel and as mult_csr_base
+// (reference csr.c:4-13), but every HBM access is a full-width contiguous one,
+// and y leaves as one aligned 64-element store per workgroup.
+template <typename T> struct alignas(2 * sizeof(T)) xv_pair { T x, v; };
+
+template <typename T, int IPL>
+__global__ __launch_bounds__(kWave) void csr_rows_lds_kernel(int rows, const int *__restrict__ row_ptr,
+                                                             const int *__restrict__ col,
+                                                             const T *__restrict__ val,
+                                                             const int *__restrict__ row_map,
+                                                             const T *__restrict__ x, T *__restrict__ y)
+{
+    constexpr int kCap = kWave * IPL;
+    __shared__ xv_pair<T> stage[kCap];
+    const int blk = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int lane = threadIdx.x;
+    const int row = blk * kWave + lane;
+    const int last = min(blk * kWave + kWave, rows);
+    const int rs = row_ptr[min(row, rows)];
+    const int re = row < rows ? row_ptr[row + 1] : rs;
+    const int run_begin = __builtin_amdgcn_readfirstlane(rs);
+    const int run_end = row_ptr[last];
+    T acc = 0;
+    auto load_chunk = [&](int e0, int (&cc)[IPL], T (&vv)[IPL]) {
+        const int n = min(kCap, run_end - e0);
+#pragma unroll
+        for (int i = 0; i < IPL; i++) cc[i] = col[e0 + min(lane + i * kWave, n - 1)];
+#pragma unroll
+        for (int i = 0; i < IPL; i++) vv[i] = val[e0 + min(lane + i * kWave, n - 1)];
+    };
+    int cc[IPL];
+    T vv[IPL];
+    if (run_begin < run_end) load_chunk(run_begin, cc, vv);
+    for (int e0 = run_begin; e0 < run_end; e0 += kCap) {
+        const int n = min(kCap, run_end - e0);
+        T xx[IPL];
+        int cnext[IPL];
+        T vnext[IPL];
+#pragma unroll
+        for (int i = 0; i < IPL; i++) xx[i] = x[cc[i]];
+        // the next chunk's stream loads stay in flight during this chunk's row sums
+        if (e0 + kCap < run_end) load_chunk(e0 + kCap, cnext, vnext);
+#pragma unroll
+        for (int i = 0; i < IPL; i++) stage[lane + i * kWave] = xv_pair<T>{xx[i], vv[i]};
+#pragma unroll
+        for (int i = 0; i < IPL; i++) { cc[i] = cnext[i]; vv[i] = vnext[i]; }
+        __syncthreads();
+        int k = max(rs, e0) - e0;
+        const int kend = min(re, e0 + n) - e0;
+        for (; k + 4 <= kend; k += 4) {
+            xv_pair<T> p[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) p[u] = stage[k + u];
+#pragma unroll
+            for (int u = 0; u < 4; u++) acc = fma_t(p[u].x, p[u].v, acc);
+        }
+        for (; k < kend; k++) acc = fma_t(stage[k].x, stage[k].v, acc);
+        __syncthreads();
+    }
+    if (row < rows) y[row_map ? row_map[row] : row] = acc;
+}
+
 // --------------------------------------------------------- CSR, G lanes/row --
 
-template <typename T, int G>
+// Each group of G lanes owns R consecutive rows and walks them side by side, so
+// that R (column, value) loads and R gathers per lane are in flight together;
+// lane i of a row adds entries i, i+G, i+2G, ... and the G partial sums are
+// combined by the DPP butterfly.  The first R lanes of the group store the R
+// results, so a wave writes one contiguous run of 64/G*R elements of y.
+template <typename T, int G, int R>
 __global__ __launch_bounds__(kBlock) void csr_vector_kernel(int rows, const int *__restrict__ row_ptr,
                                                             const int *__restrict__ col,
                                                             const T *__restrict__ val,
                                                             const int *__restrict__ row_map,
                                                             const T *__restrict__ x, T *__restrict__ y)
 {
-    constexpr int kRowsPerBlock = kBlock / G;
-    unsigned b = xcd_contiguous_block(blockIdx.x, gridDim.x);
-    int row = (int)(b * kRowsPerBlock + threadIdx.x / G);
-    int lane = threadIdx.x % G;
-    T s = 0;
-    if (row < rows) {
-        int beg = row_ptr[row], end = row_ptr[row + 1];
-        for (int l = beg + lane; l < end; l += G) s = fma_t(x[col[l]], val[l], s);
+    static_assert(R <= G, "the first R lanes of a group store its R rows");
+    constexpr int kRowsPerBlock = kBlock / G * R;
+    const unsigned b = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int lane = threadIdx.x % G;
+    const int row0 = (int)(b * kRowsPerBlock) + (int)(threadIdx.x / G) * R;
+    int ptr[R + 1];
+#pragma unroll
+    for (int r = 0; r <= R; r++) ptr[r] = row_ptr[min(row0 + r, rows)];
+    int longest = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) longest = max(longest, ptr[r + 1] - ptr[r]);
+    T s[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) s[r] = 0;
+    for (int off = lane; off < longest; off += G) {
+        int c[R];
+        T v[R], xv[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) c[r] = ptr[r] + off < ptr[r + 1] ? col[ptr[r] + off] : 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) v[r] = ptr[r] + off < ptr[r + 1] ? val[ptr[r] + off] : (T)0;
+#pragma unroll
+        for (int r = 0; r < R; r++) xv[r] = x[c[r]];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if (ptr[r] + off < ptr[r + 1]) s[r] = fma_t(xv[r], v[r], s[r]);
     }
-    s = group_sum<G>(s);
-    if (lane == 0 && row < rows) y[row_map ? row_map[row] : row] = s;
+    T mine = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const T total = group_sum<G>(s[r]);
+        if (lane == r) mine = total;
+    }
+    const int row = row0 + lane;
+    if (lane < R && row < rows) y[row_map ? row_map[row] : row] = mine;
 }
 
 // ------------------------------------------- sliced formats, slice height 64 --
@@ -426,14 +523,21 @@ template <typename T> static int launch_csr_vector(const spmv_hip_matrix *m, con
     const int *rp = m->d_row_ptr, *cj = m->d_col;
     const T *va = (const T *)m->d_val;
     int rows = m->rows;
-#define SPMV_VEC_CASE(G)                                                                              \
-    case G:                                                                                           \
-        hipLaunchKernelGGL((csr_vector_kernel<T, G>), dim3(cdiv(rows, kBlock / G)), dim3(kBlock), 0,  \
+    // rows walked side by side by one lane group: variant 1 -> 1, 2 -> 2, 3 -> 4, 4 -> 8 (never more than
+    // the group has lanes); variant 0 -> 4 for groups of 16 lanes and more, else 1 (what measurements favour)
+    static const int kRowsOfVariant[] = {0, 1, 2, 4, 8};
+    if (m->variant < 0 || m->variant > 4) { set_error("csr_vector: unknown kernel variant %d", m->variant); return 1; }
+    const int side = m->variant == 0 ? (m->lanes_per_row >= 16 ? 4 : 1)
+                                     : std::min(kRowsOfVariant[m->variant], m->lanes_per_row);
+#define SPMV_VEC_ONE(G, R)                                                                            \
+    case G * 16 + R:                                                                                  \
+        hipLaunchKernelGGL((csr_vector_kernel<T, G, R>), dim3(cdiv(rows, kBlock / G * R)), dim3(kBlock), 0, \
                            st, rows, rp, cj, va, m->d_row_map, x, y);                                 \
         break;
-    switch (m->lanes_per_row) {
-        SPMV_VEC_CASE(2)
-        SPMV_VEC_CASE(4)
+#define SPMV_VEC_CASE(G) SPMV_VEC_ONE(G, 1) SPMV_VEC_ONE(G, 2) SPMV_VEC_ONE(G, 4) SPMV_VEC_ONE(G, 8)
+    switch (m->lanes_per_row * 16 + side) {
+        SPMV_VEC_ONE(2, 1) SPMV_VEC_ONE(2, 2)
+        SPMV_VEC_ONE(4, 1) SPMV_VEC_ONE(4, 2) SPMV_VEC_ONE(4, 4)
         SPMV_VEC_CASE(8)
         SPMV_VEC_CASE(16)
         SPMV_VEC_CASE(32)
@@ -443,6 +547,7 @@ template <typename T> static int launch_csr_vector(const spmv_hip_matrix *m, con
         return 1;
     }
 #undef SPMV_VEC_CASE
+#undef SPMV_VEC_ONE
     return 0;
 }
 
@@ -459,9 +564,14 @@ int variant_candidates(const spmv_hip_matrix *m, int *out, int max_out)
         for (int v : kSlicedVariants)
             if (n < max_out) out[n++] = v;
     } else if (m->format == SPMV_HIP_CSR_VECTOR) {
-        // for the vector CSR kernel the "variant" tried by analyze is the lanes-per-row group size
+        // vector CSR: candidates are (lanes per row) + 256 * (variant = rows side by side, see launch_csr_vector)
         for (int g = 2; g <= 64; g *= 2)
-            if (n < max_out) out[n++] = g;
+            for (int v = 1; v <= 3; v++)
+                if ((1 << (v - 1)) <= g && n < max_out) out[n++] = g + 256 * v;
+    } else if (m->format == SPMV_HIP_CSR_SCALAR) {
+        // LDS chunk sizes of the staged lane-per-row kernel (all give the same bits)
+        for (int v : {0, 2, 3, 4})
+            if (n < max_out) out[n++] = v;
     } else if (n < max_out) {
         out[n++] = 0;
     }
@@ -513,6 +623,31 @@ template <typename T> static int launch_sliced(const spmv_hip_matrix *m, const T
     return 0;
 }
 
+// scalar CSR variants: 0, 2, 3, 4 = LDS-staged with 512, 1024, 256, 2048 entries per chunk; 1 = plain
+template <typename T> static int launch_csr_scalar(const spmv_hip_matrix *m, const T *x, T *y, hipStream_t st)
+{
+    const T *va = (const T *)m->d_val;
+    const dim3 grid(cdiv(m->rows, kWave)), block(kWave);
+#define SPMV_ROWS_CASE(V, I)                                                                             \
+    case V:                                                                                              \
+        hipLaunchKernelGGL((csr_rows_lds_kernel<T, I>), grid, block, 0, st, m->rows, m->d_row_ptr, m->d_col, va, \
+                           m->d_row_map, x, y);                                                          \
+        break;
+    switch (m->variant) {
+        SPMV_ROWS_CASE(0, 8)
+        SPMV_ROWS_CASE(2, 16)
+        SPMV_ROWS_CASE(3, 4)
+        SPMV_ROWS_CASE(4, 32)
+    case 1:
+        hipLaunchKernelGGL((csr_scalar_kernel<T>), dim3(cdiv(m->rows, kBlock)), dim3(kBlock), 0, st, m->rows,
+                           m->d_row_ptr, m->d_col, va, m->d_row_map, x, y);
+        break;
+    default: set_error("scalar CSR: unknown kernel variant %d", m->variant); return 1;
+    }
+#undef SPMV_ROWS_CASE
+    return 0;
+}
+
 template <typename T> static int launch_tiles(const spmv_hip_matrix *m, const T *x, T *y, hipStream_t st)
 {
     const bool bal = m->format == SPMV_HIP_CSR_BAL;
@@ -553,10 +688,7 @@ template <typename T> static int launch_mult_t(const spmv_hip_matrix *m, const T
     int rc = 0;
     if (m->rows == 0) return 0;
     switch (m->format) {
-    case SPMV_HIP_CSR_SCALAR:
-        hipLaunchKernelGGL((csr_scalar_kernel<T>), dim3(cdiv(m->rows, kBlock)), dim3(kBlock), 0, st, m->rows,
-                           m->d_row_ptr, m->d_col, (const T *)m->d_val, m->d_row_map, x, y);
-        break;
+    case SPMV_HIP_CSR_SCALAR: rc = launch_csr_scalar<T>(m, x, y, st); break;
     case SPMV_HIP_CSR_VECTOR: rc = launch_csr_vector<T>(m, x, y, st); break;
     case SPMV_HIP_CSR_MERGE:
     case SPMV_HIP_CSR_BAL: rc = launch_tiles<T>(m, x, y, st); break;

@@ -60,6 +60,29 @@ def test_csr_scalar_bitwise(g):
     assert bits_equal(y, g["y_coo"])            # the driver's own check (driver_spmv.c:274-289)
 
 
+SCALAR_VARIANTS = [0, 1, 2, 3, 4]               # LDS-staged chunk sizes and the plain lane-per-row kernel
+
+
+@pytest.mark.parametrize("alignment", [1, 4])
+def test_csr_scalar_variants_all_bitwise(orc, g, alignment):
+    rows, cols = int(g["rows"]), int(g["cols"])
+    csr = (g["csr1_row_ptr"], g["csr1_col"], g["csr1_val"])
+    x32 = g["x"].astype(np.float32)
+    y32 = orc.mult_csr_base_f32(csr[0], csr[1], csr[2].astype(np.float32), x32)
+    for dtype, xin, want in ((S.F64, g["x"], g["y_csr_base"]), (S.F32, x32.astype(np.float64), y32)):
+        m = Matrix.csr(rows, cols, coo_of(g), alignment, dtype, S.CSR_SCALAR)
+        for v in SCALAR_VARIANTS:
+            m.set_option("variant", v)
+            y = m.mult(xin)
+            assert bits_equal(y.astype(want.dtype), want), (v, dtype)
+        assert m.analyze(2) in SCALAR_VARIANTS
+        assert bits_equal(m.mult(xin).astype(want.dtype), want)
+        with pytest.raises(S.SpmvHipError, match="variant"):
+            m.set_option("variant", 99)
+            m.mult(xin)
+        m.free()
+
+
 @pytest.mark.parametrize("lanes", [0, 2, 4, 8, 16, 32, 64])
 def test_csr_vector(orc, g, lanes):
     # alignment 4 = the reference's csr_vec mode (driver_spmv.c:189-191)
@@ -70,6 +93,9 @@ def test_csr_vector(orc, g, lanes):
     y = m.mult(g["x"])
     assert rel(orc, y, g["y_csr_base"]) <= TOL_REASSOC
     assert rel(orc, y, g["y_csr_vec"]) <= TOL_REASSOC
+    for v in (1, 2, 3, 4):                          # 1, 2, 4, 8 rows side by side per lane group: same sums
+        m.set_option("variant", v)
+        assert bits_equal(m.mult(g["x"]), y), v
 
 
 @pytest.mark.parametrize("items", [0, 256, 2048])
