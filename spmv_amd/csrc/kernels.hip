@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kBlock) void csr_scalar_kernel(int rows, const int 
 // and y leaves as one aligned 64-element store per workgroup.
 template <typename T> struct alignas(2 * sizeof(T)) xv_pair { T x, v; };
 
-template <typename T, int IPL>
+template <typename T, int IPL, bool NT>
 __global__ __launch_bounds__(kWave) void csr_rows_lds_kernel(int rows, const int *__restrict__ row_ptr,
                                                              const int *__restrict__ col,
                                                              const T *__restrict__ val,
@@ -113,16 +113,24 @@ __global__ __launch_bounds__(kWave) void csr_rows_lds_kernel(int rows, const int
     const int run_end = row_ptr[last];
     T acc = 0;
     auto load_chunk = [&](int e0, int (&cc)[IPL], T (&vv)[IPL]) {
-        const int n = min(kCap, run_end - e0);
 #pragma unroll
-        for (int i = 0; i < IPL; i++) cc[i] = col[e0 + min(lane + i * kWave, n - 1)];
+        for (int i = 0; i < IPL; i++) {
+            const int *p = col + min(max(e0 + lane + i * kWave, run_begin), run_end - 1);
+            cc[i] = NT ? __builtin_nontemporal_load(p) : *p;
+        }
 #pragma unroll
-        for (int i = 0; i < IPL; i++) vv[i] = val[e0 + min(lane + i * kWave, n - 1)];
+        for (int i = 0; i < IPL; i++) {
+            const T *p = val + min(max(e0 + lane + i * kWave, run_begin), run_end - 1);
+            vv[i] = NT ? __builtin_nontemporal_load(p) : *p;
+        }
     };
     int cc[IPL];
     T vv[IPL];
-    if (run_begin < run_end) load_chunk(run_begin, cc, vv);
-    for (int e0 = run_begin; e0 < run_end; e0 += kCap) {
+    // chunks start on 32-entry boundaries of the arrays, so every load instruction covers whole
+    // 128-byte lines (lanes before the run's first entry repeat it)
+    const int first = run_begin & ~31;
+    if (run_begin < run_end) load_chunk(first, cc, vv);
+    for (int e0 = first; e0 < run_end; e0 += kCap) {
         const int n = min(kCap, run_end - e0);
         T xx[IPL];
         int cnext[IPL];
@@ -570,7 +578,7 @@ int variant_candidates(const spmv_hip_matrix *m, int *out, int max_out)
                 if ((1 << (v - 1)) <= g && n < max_out) out[n++] = g + 256 * v;
     } else if (m->format == SPMV_HIP_CSR_SCALAR) {
         // LDS chunk sizes of the staged lane-per-row kernel (all give the same bits)
-        for (int v : {0, 2, 3, 4})
+        for (int v : {0, 2, 3, 4, 8, 10, 11, 12})
             if (n < max_out) out[n++] = v;
     } else if (n < max_out) {
         out[n++] = 0;
@@ -623,16 +631,18 @@ template <typename T> static int launch_sliced(const spmv_hip_matrix *m, const T
     return 0;
 }
 
-// scalar CSR variants: 0, 2, 3, 4 = LDS-staged with 512, 1024, 256, 2048 entries per chunk; 1 = plain
+// scalar CSR variants: 0, 2, 3, 4 = LDS-staged with 512, 1024, 256, 2048 entries per chunk, +8 = the same
+// with non-temporal loads of the streamed arrays (for matrices far larger than the caches); 1 = plain
 template <typename T> static int launch_csr_scalar(const spmv_hip_matrix *m, const T *x, T *y, hipStream_t st)
 {
     const T *va = (const T *)m->d_val;
     const dim3 grid(cdiv(m->rows, kWave)), block(kWave);
-#define SPMV_ROWS_CASE(V, I)                                                                             \
+#define SPMV_ROWS_ONE(V, I, NT)                                                                          \
     case V:                                                                                              \
-        hipLaunchKernelGGL((csr_rows_lds_kernel<T, I>), grid, block, 0, st, m->rows, m->d_row_ptr, m->d_col, va, \
-                           m->d_row_map, x, y);                                                          \
+        hipLaunchKernelGGL((csr_rows_lds_kernel<T, I, NT>), grid, block, 0, st, m->rows, m->d_row_ptr, m->d_col, \
+                           va, m->d_row_map, x, y);                                                      \
         break;
+#define SPMV_ROWS_CASE(V, I) SPMV_ROWS_ONE(V, I, false) SPMV_ROWS_ONE(V + 8, I, true)
     switch (m->variant) {
         SPMV_ROWS_CASE(0, 8)
         SPMV_ROWS_CASE(2, 16)
@@ -645,6 +655,7 @@ template <typename T> static int launch_csr_scalar(const spmv_hip_matrix *m, con
     default: set_error("scalar CSR: unknown kernel variant %d", m->variant); return 1;
     }
 #undef SPMV_ROWS_CASE
+#undef SPMV_ROWS_ONE
     return 0;
 }
 

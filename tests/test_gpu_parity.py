@@ -60,7 +60,8 @@ def test_csr_scalar_bitwise(g):
     assert bits_equal(y, g["y_coo"])            # the driver's own check (driver_spmv.c:274-289)
 
 
-SCALAR_VARIANTS = [0, 1, 2, 3, 4]               # LDS-staged chunk sizes and the plain lane-per-row kernel
+# LDS-staged chunk sizes 0, 2, 3, 4 (+8: non-temporal loads), 1 = plain
+SCALAR_VARIANTS = [0, 1, 2, 3, 4, 8, 10, 11, 12]
 
 
 @pytest.mark.parametrize("alignment", [1, 4])
