@@ -372,7 +372,7 @@ __global__ __launch_bounds__(kBlock) void sliced_any_kernel(int rows, int height
 // tile that lies inside a single row reduces its registers directly.
 constexpr int kLongRow = 48;
 
-template <typename T, int IPL>
+template <typename T, int IPL, int MODE>
 __global__ __launch_bounds__(kWave) void wave_tile_kernel(int list_len, const int *__restrict__ row_end_list,
                                                           const int *__restrict__ row_index,
                                                           const int *__restrict__ tile_coord,
@@ -390,37 +390,55 @@ __global__ __launch_bounds__(kWave) void wave_tile_kernel(int list_len, const in
     const int a1 = tile_coord[2 * t + 2], b1 = tile_coord[2 * t + 3];
     const int nr = a1 - a0, nz = b1 - b0;
 
-    // phase 1: IPL coalesced (column, value) loads per lane, then the gathers, all in flight together
-    T pp[IPL];
+    // phase 1: coalesced (column, value) loads, then the gathers, all in flight together.  The loads
+    // start on a 32-entry boundary of the arrays so that each instruction covers whole 128-byte
+    // lines (one more, mostly idle, load per lane than the tile has items per lane); lanes outside
+    // the tile repeat its first or last entry.
+    constexpr int kLoads = MODE ? IPL + 1 : IPL;
+    const int first = MODE ? (b0 & ~31) - b0 : 0;   // position of lane 0's first load relative to the tile
+    T pp[kLoads];
     if (nz > 0) {
-        int cc[IPL];
-        T vv[IPL], xx[IPL];
+        int cc[kLoads];
+        T vv[kLoads], xx[kLoads];
 #pragma unroll
-        for (int i = 0; i < IPL; i++) cc[i] = col[b0 + min(lane + i * kWave, nz - 1)];
+        for (int i = 0; i < kLoads; i++) {
+            const int *p = col + b0 + min(max(first + lane + i * kWave, 0), nz - 1);
+            cc[i] = MODE == 2 ? __builtin_nontemporal_load(p) : *p;
+        }
 #pragma unroll
-        for (int i = 0; i < IPL; i++) vv[i] = val[b0 + min(lane + i * kWave, nz - 1)];
+        for (int i = 0; i < kLoads; i++) {
+            const T *p = val + b0 + min(max(first + lane + i * kWave, 0), nz - 1);
+            vv[i] = MODE == 2 ? __builtin_nontemporal_load(p) : *p;
+        }
 #pragma unroll
-        for (int i = 0; i < IPL; i++) xx[i] = x[cc[i]];
+        for (int i = 0; i < kLoads; i++) xx[i] = x[cc[i]];
 #pragma unroll
-        for (int i = 0; i < IPL; i++) pp[i] = lane + i * kWave < nz ? vv[i] * xx[i] : (T)0;
+        for (int i = 0; i < kLoads; i++) {
+            const int k = first + lane + i * kWave;
+            pp[i] = k >= 0 && k < nz ? vv[i] * xx[i] : (T)0;
+        }
     } else {
 #pragma unroll
-        for (int i = 0; i < IPL; i++) pp[i] = 0;
+        for (int i = 0; i < kLoads; i++) pp[i] = 0;
     }
 
     if (nr == 0) {                               // the tile is a piece of one row
         T s = 0;
 #pragma unroll
-        for (int i = 0; i < IPL; i++) s += pp[i];
+        for (int i = 0; i < kLoads; i++) s += pp[i];
         s = group_sum<kWave>(s);
         if (lane == 0) { row_carry[t] = a1; val_carry[t] = s; }
         return;
     }
 
 #pragma unroll
+    for (int i = 0; i < kLoads; i++) {
+        const int k = first + lane + i * kWave;
+        if (k >= 0 && k < nz) prod[k] = pp[i];
+    }
+#pragma unroll
     for (int i = 0; i < IPL; i++) {
-        int k = lane + i * kWave;
-        if (k < nz) prod[k] = pp[i];
+        const int k = lane + i * kWave;
         if (k < nr) rend[k] = row_end_list[a0 + k] - b0;
     }
     __syncthreads();
@@ -580,6 +598,9 @@ int variant_candidates(const spmv_hip_matrix *m, int *out, int max_out)
         // LDS chunk sizes of the staged lane-per-row kernel (all give the same bits)
         for (int v : {0, 2, 3, 4, 8, 10, 11, 12})
             if (n < max_out) out[n++] = v;
+    } else if (m->format == SPMV_HIP_CSR_MERGE || m->format == SPMV_HIP_CSR_BAL) {
+        for (int v : {0, 1})
+            if (n < max_out) out[n++] = v;
     } else if (n < max_out) {
         out[n++] = 0;
     }
@@ -673,11 +694,17 @@ template <typename T> static int launch_tiles(const spmv_hip_matrix *m, const T 
         if (!bal && m->rows > 0) SPMV_HIP_TRY(hipMemsetAsync(y, 0, (size_t)m->rows * sizeof(T), st), return 1);
         return 0;
     }
+    // variant 0: loads start at the tile's first entry; 1: line-aligned non-temporal loads (MODE 2)
+    if (m->variant != 0 && m->variant != 1) { set_error("tile kernel: unknown kernel variant %d", m->variant); return 1; }
     // merge tiles hold items_per_tile path items; balanced tiles hold that many non-zeros
-#define SPMV_WTILE_CASE(I)                                                                               \
+#define SPMV_WTILE_CASE(I)                                                                              \
     case I:                                                                                              \
-        hipLaunchKernelGGL((wave_tile_kernel<T, I>), dim3(m->ntiles), dim3(kWave), 0, st, list_len, list,   \
-                           index, m->d_tile_coord, m->d_col, va, x, y, m->d_row_carry, vc);              \
+        if (m->variant == 0)                                                                             \
+            hipLaunchKernelGGL((wave_tile_kernel<T, I, 0>), dim3(m->ntiles), dim3(kWave), 0, st, list_len, list, \
+                               index, m->d_tile_coord, m->d_col, va, x, y, m->d_row_carry, vc);          \
+        else                                                                                             \
+            hipLaunchKernelGGL((wave_tile_kernel<T, I, 2>), dim3(m->ntiles), dim3(kWave), 0, st, list_len, list, \
+                               index, m->d_tile_coord, m->d_col, va, x, y, m->d_row_carry, vc);          \
         break;
     switch (m->items_per_tile % kWave ? 0 : m->items_per_tile / kWave) {
         SPMV_WTILE_CASE(4)

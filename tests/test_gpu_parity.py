@@ -115,6 +115,12 @@ def test_csr_merge(orc, g, items):
     y = m.mult(g["x"])
     assert rel(orc, y, g["y_csr_base"]) <= TOL_REASSOC
     assert rel(orc, y, g["y_csr_merge_t8"]) <= TOL_REASSOC
+    m.set_option("variant", 1)                      # line-aligned non-temporal loads
+    assert rel(orc, m.mult(g["x"]), g["y_csr_base"]) <= TOL_REASSOC
+    assert m.analyze(2) in (0, 1)
+    with pytest.raises(S.SpmvHipError, match="variant"):
+        m.set_option("variant", 7)
+        m.mult(g["x"])
 
 
 @pytest.mark.parametrize("chunk", [0, 256, 1024])
@@ -125,6 +131,8 @@ def test_csr_bal_handles_empty_rows_too(orc, g, chunk):
     assert rel(orc, y, g["y_csr_base"]) <= TOL_REASSOC
     if "y_csr_bal_t8" in g:
         assert rel(orc, y, g["y_csr_bal_t8"]) <= TOL_REASSOC
+    m.set_option("variant", 1)
+    assert rel(orc, m.mult(g["x"]), g["y_csr_base"]) <= TOL_REASSOC
 
 
 def test_csr_vector_analyze_picks_a_group_size(orc, g):
