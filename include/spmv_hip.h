@@ -141,6 +141,22 @@ spmv_hip_matrix *spmv_hip_create_from_device_csr(int format, int rows, int colum
                                                  const int *d_row_ptr, const int *d_col, const void *d_val,
                                                  int dtype, int64_t p0, int64_t p1, void *stream);
 
+/* ---- automatic format choice -------------------------------------------------
+ * The reference leaves the format to the user (MODE string, spmv.run:20,
+ * driver_spmv.c:186-261) and tunes only inside SELL-C-sigma
+ * (sellcs_analyze_matrix, sellcs_analyzer.c:46-120).  These creators extend
+ * that trial to the formats themselves: merge-path CSR, lane-per-row CSR,
+ * vector CSR, SELLP and SELL-64-1024 are each built from the same CSR (the
+ * sliced ones only if they store at most 2x the non-zeros), tuned as by
+ * spmv_hip_analyze with `reps` timed products per kernel variant, and the
+ * fastest handle is returned (spmv_hip_get_info tells which).  create_auto
+ * sorts the caller's coo like the other creators; the device variant adopts the
+ * caller's CSR arrays when a CSR-family format wins. */
+spmv_hip_matrix *spmv_hip_create_auto(int rows, int columns, int nnz, struct mtx *coo, int dtype, int reps);
+spmv_hip_matrix *spmv_hip_create_auto_from_device_csr(int rows, int columns, int64_t nnz, const int *d_row_ptr,
+                                                      const int *d_col, const void *d_val, int dtype, int reps,
+                                                      void *stream);
+
 /* ---- multiply --------------------------------------------------------------- */
 
 /* mult_X(matrix, x, y) (driver_spmv.c:184,276): host vectors, x[columns],

@@ -43,6 +43,8 @@ SIGNATURES = {
     "spmv_hip_create_sellp": (_vp, [_i, _i, _i, _vp, _vp, _vp, _i, _i]),
     "spmv_hip_create_sell": (_vp, [_i, _i, _i, _vp, _vp, _vp, _i, _i, _i64]),
     "spmv_hip_create_from_device_csr": (_vp, [_i, _i, _i, _i64, _vp, _vp, _vp, _i, _i64, _i64, _vp]),
+    "spmv_hip_create_auto": (_vp, [_i, _i, _i, _vp, _i, _i]),
+    "spmv_hip_create_auto_from_device_csr": (_vp, [_i, _i, _i64, _vp, _vp, _vp, _i, _i, _vp]),
     "spmv_hip_mult": (_i, [_vp, _vp, _vp]),
     "spmv_hip_mult_dev": (_i, [_vp, _vp, _vp, _vp]),
     "spmv_hip_set_row_map": (_i, [_vp, _vp]),

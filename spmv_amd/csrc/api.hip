@@ -406,14 +406,17 @@ int spmv_hip_set_row_map(spmv_hip_matrix *m, const int *d_row_map)
     return 0;
 }
 
-int spmv_hip_analyze(spmv_hip_matrix *m, int reps)
+// Times every kernel variant of the handle `reps` times and keeps the fastest; *best_ms_out (optional)
+// receives the summed time of the winner's `reps` launches (handles with a single variant are timed
+// only when the caller asks for the time).
+static int analyze_impl(spmv_hip_matrix *m, int reps, float *best_ms_out)
 {
-    clear_error();
-    if (!m) { set_error("NULL handle"); return 1; }
+    if (best_ms_out) *best_ms_out = 0;
     if (reps < 1) reps = 3;
     int cand[32];
     const int n = variant_candidates(m, cand, 32);
-    if (n <= 1 || m->rows == 0 || m->d_row_map) return 0;   // row-mapped handles write outside d_y
+    if (m->rows == 0 || m->d_row_map) return 0;             // row-mapped handles write outside d_y
+    if (n <= 1 && !best_ms_out) return 0;
     if (ensure_vectors(m)) return 1;
     const size_t es = dtype_size(m->dtype);
     SPMV_HIP_TRY(hipMemset(m->d_x, 0, (size_t)std::max(m->columns, 1) * es), return 1);
@@ -446,7 +449,95 @@ int spmv_hip_analyze(spmv_hip_matrix *m, int reps)
     (void)hipEventDestroy(e1);
     apply(rc ? keep : best);
     if (rc && !g_error[0]) set_error("analyze: timing a kernel variant failed");
+    if (!rc && best_ms_out) *best_ms_out = best_ms;
     return rc;
+}
+
+int spmv_hip_analyze(spmv_hip_matrix *m, int reps)
+{
+    clear_error();
+    if (!m) { set_error("NULL handle"); return 1; }
+    return analyze_impl(m, reps, nullptr);
+}
+
+// Candidate formats of the automatic choice, in build order.  The sliced layouts are skipped when they
+// would store more than kAutoMaxPadding times the non-zeros.
+static const int kAutoFormats[] = {SPMV_HIP_CSR_MERGE, SPMV_HIP_CSR_SCALAR, SPMV_HIP_CSR_VECTOR, SPMV_HIP_SELLP, SPMV_HIP_SELL};
+constexpr double kAutoMaxPadding = 2.0;
+
+static spmv_hip_matrix *view_of_device_csr(int format, int rows, int columns, int64_t nnz, const int *d_row_ptr,
+                                           const int *d_col, const void *d_val, int dtype, hipStream_t st)
+{
+    spmv_hip_matrix *m = new_handle(format, dtype, rows, columns, nnz);
+    if (!m) return nullptr;
+    m->owns_csr = false;
+    m->stored = nnz;
+    m->d_row_ptr = const_cast<int *>(d_row_ptr);
+    m->d_col = const_cast<int *>(d_col);
+    m->d_val = const_cast<void *>(d_val);
+    m->max_padding = kAutoMaxPadding;
+    const int64_t p0 = format == SPMV_HIP_SELL ? kDefaultC : 0, p1 = format == SPMV_HIP_SELL ? 1024 : 0;
+    if (finish_from_device_csr(m, p0, p1, dtype == SPMV_HIP_F64, st)) {
+        spmv_hip_free(m);
+        return nullptr;
+    }
+    return m;
+}
+
+// Builds each candidate over the same device CSR, tunes and times it, keeps the fastest.
+static spmv_hip_matrix *auto_from_device_csr(int rows, int columns, int64_t nnz, const int *d_row_ptr, const int *d_col,
+                                             const void *d_val, int dtype, int reps, hipStream_t st)
+{
+    spmv_hip_matrix *best = nullptr;
+    float best_ms = 0;
+    for (int format : kAutoFormats) {
+        spmv_hip_matrix *m = view_of_device_csr(format, rows, columns, nnz, d_row_ptr, d_col, d_val, dtype, st);
+        if (!m) continue;                                    // e.g. too much padding: not a candidate
+        float ms = 0;
+        if (analyze_impl(m, reps, &ms)) { spmv_hip_free(m); continue; }
+        if (!best || ms < best_ms) {
+            if (best) spmv_hip_free(best);
+            best = m; best_ms = ms;
+        } else {
+            spmv_hip_free(m);
+        }
+    }
+    if (best) {
+        clear_error();                                       // skipped candidates left their reason behind
+    } else if (!g_error[0]) {
+        set_error("create_auto: no format could be built");
+    }
+    return best;
+}
+
+spmv_hip_matrix *spmv_hip_create_auto_from_device_csr(int rows, int columns, int64_t nnz, const int *d_row_ptr,
+                                                      const int *d_col, const void *d_val, int dtype, int reps,
+                                                      void *stream)
+{
+    clear_error();
+    if (check_dims(rows, columns, nnz, dtype)) return nullptr;
+    if (nnz > 0x7fffffffLL) { set_error("nnz %lld exceeds the 32-bit row pointers of CSR", (long long)nnz); return nullptr; }
+    if (!d_row_ptr || (nnz > 0 && (!d_col || !d_val))) { set_error("NULL device CSR array"); return nullptr; }
+    return auto_from_device_csr(rows, columns, nnz, d_row_ptr, d_col, d_val, dtype, reps, (hipStream_t)stream);
+}
+
+spmv_hip_matrix *spmv_hip_create_auto(int rows, int columns, int nnz, struct mtx *coo, int dtype, int reps)
+{
+    // the CSR arrays live in a merge-path handle; the winner either is that handle, takes the
+    // arrays over from it (CSR family), or holds its own sliced copy
+    spmv_hip_matrix *base = create_from_coo(SPMV_HIP_CSR_MERGE, rows, columns, nnz, 1, coo, dtype, 0, 0);
+    if (!base) return nullptr;
+    spmv_hip_matrix *best = auto_from_device_csr(rows, columns, nnz, base->d_row_ptr, base->d_col, base->d_val, dtype,
+                                                 reps, nullptr);
+    if (!best) { spmv_hip_free(base); return nullptr; }
+    if (best->d_row_ptr == base->d_row_ptr) {                // a CSR-family view of base's arrays
+        best->owns_csr = true;
+        base->owns_csr = false;
+        const int64_t csr_bytes = (int64_t)sizeof(int) * (rows + 1) + (int64_t)std::max(nnz, 1) * (sizeof(int) + dtype_size(dtype));
+        best->device_bytes += csr_bytes;
+    }
+    spmv_hip_free(base);
+    return best;
 }
 
 int spmv_hip_get_info(const spmv_hip_matrix *m, spmv_hip_info *info)

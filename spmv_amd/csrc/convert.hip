@@ -210,6 +210,11 @@ int build_sliced(spmv_hip_matrix *m, const int *d_row_ptr, const int *d_col, con
         int64_t total = 0;
         for (int s = 0; s < m->nslices; s++) { sp[s] = total; total += (int64_t)width[s] * H; }
         sp[m->nslices] = total;
+        if (m->max_padding > 0 && (double)total > m->max_padding * (double)std::max<int64_t>(m->nnz, 1)) {
+            set_error("sliced layout would store %lld entries for %lld non-zeros (limit %.1fx)", (long long)total,
+                      (long long)m->nnz, m->max_padding);
+            break;
+        }
         m->stored = total;
         if (dev_alloc(m, &m->d_slice_ptr, sp.size())) break;
         if (dev_alloc(m, &m->d_scol, (size_t)total)) break;

@@ -135,6 +135,7 @@ static spmv_hip_matrix *create_for_mode(const char *mode, int rows, int cols, in
     if (!strcmp(mode, "csr_merge")) return spmv_hip_create_csr_merge(rows, cols, nnz, coo, dtype, 0);
     if (!strcmp(mode, "csr_bal")) return spmv_hip_create_csr_bal(rows, cols, nnz, coo, dtype, 0);
     if (!strcmp(mode, "ell")) return spmv_hip_create_ell(rows, cols, nnz, coo, dtype, 0);
+    if (!strcmp(mode, "auto")) return spmv_hip_create_auto(rows, cols, nnz, coo, dtype, 3);   /* format by trial */
     if (!strcmp(mode, "sellp_vec") || !strcmp(mode, "sellp_autovec") || !strcmp(mode, "sellp_highway") || !strcmp(mode, "sell")) {
         int *rp, *cj; double *va;
         spmv_hip_sort_coo(nnz, coo);                       /* create_csr's side effect (csr.c:167) */

@@ -47,6 +47,7 @@ struct spmv_hip_matrix {
     int lanes_per_row = 0;
     const int *d_row_map = nullptr; // CSR_SCALAR / CSR_VECTOR: matrix row k writes y[row_map[k]] (caller's array)
     int variant = 0;               // kernel variant inside the format (spmv_hip_set_option "variant")
+    double max_padding = 0;        // > 0: building a sliced layout fails when stored > max_padding * nnz
 
     // merge-path / balanced tiles
     int ntiles = 0, items_per_tile = 0;

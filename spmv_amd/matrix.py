@@ -71,6 +71,20 @@ class Matrix:
                                                 sigma))
 
     @classmethod
+    def auto(cls, rows, columns, coo, dtype=L.F64, reps=3):
+        """Fastest of merge / lane-per-row / vector CSR, SELLP, SELL-64-1024 by trial; sorts `coo` in place."""
+        coo = _as_coo(coo)
+        return cls(L.lib().spmv_hip_create_auto(rows, columns, len(coo), _ptr(coo), dtype, reps))
+
+    @classmethod
+    def auto_from_device_csr(cls, rows, columns, nnz, d_row_ptr, d_col, d_val, dtype=L.F64, reps=3, stream=0,
+                             keepalive=None):
+        m = cls(L.lib().spmv_hip_create_auto_from_device_csr(rows, columns, nnz, d_row_ptr, d_col, d_val, dtype, reps,
+                                                             stream))
+        m._keepalive = keepalive
+        return m
+
+    @classmethod
     def from_device_csr(cls, fmt, rows, columns, nnz, d_row_ptr, d_col, d_val, dtype=L.F64, p0=0, p1=0, stream=0,
                         keepalive=None):
         """CSR arrays already in HBM (raw device addresses).  `keepalive` is held
@@ -217,4 +231,6 @@ def create(mode: str, rows: int, columns: int, coo: np.ndarray, dtype=L.F64, sig
         if mode == "sell":
             return Matrix.sell(rows, columns, rp, cj, va, dtype, 0, sigma)
         return Matrix.sellp(rows, columns, rp, cj, va, dtype)
+    if mode == "auto":                                       # no reference MODE: format chosen by trial
+        return Matrix.auto(rows, columns, coo, dtype)
     raise ValueError("Error: Unknown execution mode.")       # :258-260

@@ -40,6 +40,7 @@ FORMATS = {
     "ell": (S.ELL, 0, 0),
     "sellp_vec": (S.SELLP, 0, 0),
     "sell": (S.SELL, 64, 1024),
+    "auto": (-1, 0, 0),
 }
 TOLERANCE = {S.F64: 1e-10, S.F32: 1e-5}
 
@@ -97,9 +98,14 @@ def run_matrix(name: str, scale: float, formats, dtypes, min_iters: int, min_sec
         for mode in formats:
             fmt, p0, p1 = FORMATS[mode]
             try:
-                m = Matrix.from_device_csr(fmt, rows, cols, nnz, rp.data_ptr(), cj.data_ptr(), vals.data_ptr(), dtype,
-                                           p0, p1, st)
-                m.analyze(2)
+                if mode == "auto":                            # format by trial (spmv_hip_create_auto_from_device_csr)
+                    m = Matrix.auto_from_device_csr(rows, cols, nnz, rp.data_ptr(), cj.data_ptr(), vals.data_ptr(),
+                                                    dtype, 2, st)
+                    fmt = m.info.format
+                else:
+                    m = Matrix.from_device_csr(fmt, rows, cols, nnz, rp.data_ptr(), cj.data_ptr(), vals.data_ptr(),
+                                               dtype, p0, p1, st)
+                    m.analyze(2)
                 x = x0.to(td, copy=True)                      # the power loop overwrites it
                 y = torch.empty(rows, dtype=td, device=dev)
                 m.mult_dev(x.data_ptr(), y.data_ptr(), st)
@@ -107,6 +113,8 @@ def run_matrix(name: str, scale: float, formats, dtypes, min_iters: int, min_sec
                 err = float(torch.linalg.vector_norm(y.to(torch.float64) - y_ref)) / (ref_norm or 1.0)
                 iters, seconds = timed_power_loop(m, x, y, dtype, min_iters, min_seconds, st)
                 variant = m.info.lanes_per_row * 256 + m.info.variant if fmt == S.CSR_VECTOR else m.info.variant
+                if mode == "auto":
+                    variant = f"{S.FORMAT_NAMES[fmt]}:{variant}"
                 m.free()
             except S.SpmvHipError as e:
                 lines.append(f"{mode};{name};{rows};{cols};{nnz};0;0;0;0;{'f64' if dtype == S.F64 else 'f32'};-1;0;nan;"

@@ -255,6 +255,44 @@ def test_modes_of_the_reference_driver(orc, g):
         S.create("no_such_mode", rows, cols, coo_of(g))
 
 
+AUTO_FORMATS = (S.CSR_MERGE, S.CSR_SCALAR, S.CSR_VECTOR, S.SELLP, S.SELL)
+
+
+@pytest.mark.parametrize("dtype", [S.F64, S.F32])
+def test_auto_format_choice(orc, g, dtype):
+    """create_auto returns one of its candidates, tuned; the product meets the bar of the format chosen."""
+    import torch
+    rows, cols = int(g["rows"]), int(g["cols"])
+    csr = (g["csr1_row_ptr"], g["csr1_col"], g["csr1_val"])
+    nnz = len(csr[1])
+    if dtype == S.F64:
+        xin, want, tol = g["x"], g["y_csr_base"], TOL_REASSOC
+    else:
+        x32 = g["x"].astype(np.float32)
+        xin, tol = x32.astype(np.float64), TOL_F32_VS_F32
+        want = orc.mult_csr_base_f32(csr[0], csr[1], csr[2].astype(np.float32), x32)
+    coo = coo_of(g, "in")
+    m = S.create("auto", rows, cols, coo, dtype)
+    assert bits_equal(coo["i"], g["coo_sorted_i"])            # sorted in place like every creator
+    info = m.info
+    assert info.format in AUTO_FORMATS and info.nnz == nnz and info.dtype == dtype
+    if info.format in (S.SELL, S.SELLP):
+        assert info.stored <= 2 * max(nnz, 1)
+    assert rel(orc, m.mult(xin), want) <= tol
+    m.free()
+    # the same choice over CSR arrays that stay in HBM
+    dev = torch.device("cuda:0")
+    rp = torch.from_numpy(csr[0]).to(dev)
+    cj = torch.from_numpy(csr[1]).to(dev) if nnz else torch.zeros(1, dtype=torch.int32, device=dev)
+    td = torch.float64 if dtype == S.F64 else torch.float32
+    va = torch.from_numpy(csr[2]).to(dev).to(td) if nnz else torch.zeros(1, dtype=td, device=dev)
+    m = Matrix.auto_from_device_csr(rows, cols, nnz, rp.data_ptr(), cj.data_ptr(), va.data_ptr(), dtype, 2, 0,
+                                    keepalive=(rp, cj, va))
+    assert m.info.format in AUTO_FORMATS
+    assert rel(orc, m.mult(xin), want) <= tol
+    m.free()
+
+
 def test_device_resident_path(orc, g):
     """CSR handed over in HBM, x/y resident, launches on torch's stream."""
     import torch
