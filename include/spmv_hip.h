@@ -86,6 +86,11 @@ const char *spmv_hip_last_error(void);
  * *coo is malloc'ed; release it with spmv_hip_free_coo. */
 int spmv_hip_load_mtx(const char *fname, int *rows, int *columns, int *nnz, struct mtx **coo);
 void spmv_hip_free_coo(struct mtx *coo);
+/* load_bin / save_bin (mtx.c:139-205, 207-247): int rows, int columns, long nnz,
+ * then nnz x {int i, int j, double a} (0-based).  Files written by either side
+ * are read by the other.  load_bin also range-checks the coordinates. */
+int spmv_hip_load_bin(const char *fname, int *rows, int *columns, int *nnz, struct mtx **coo);
+int spmv_hip_save_bin(const char *fname, int rows, int columns, int nnz, const struct mtx *coo);
 /* sort_mtx(nnz, coo, by_row_mtx) (mtx.c:9-34): (row, col) order, in place,
  * untouched if already sorted. */
 void spmv_hip_sort_coo(int nnz, struct mtx *coo);

@@ -263,6 +263,8 @@ def ref():
     sig = {
         "ref_block": (ci, []),
         "ref_load_mtx": (None, [C.c_char_p, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), C.POINTER(vp)]),
+        "ref_load_bin": (None, [C.c_char_p, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), C.POINTER(vp)]),
+        "ref_save_bin": (None, [C.c_char_p, ci, ci, ci, _coop]),
         "ref_free": (None, [vp]),
         "ref_sort_mtx": (None, [ci, _coop]),
         "ref_mult_mtx": (None, [ci, ci, ci, _coop, _f64p, _f64p]),

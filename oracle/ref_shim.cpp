@@ -32,6 +32,8 @@ extern "C" {
 int ref_block(void) { return _BLOCK; }
 
 void ref_load_mtx(const char *fname, int *rows, int *cols, int *nnz, struct mtx **coo) { load_mtx(fname, rows, cols, nnz, coo); }
+void ref_load_bin(const char *fname, int *rows, int *cols, int *nnz, struct mtx **coo) { load_bin(fname, rows, cols, nnz, coo); }
+void ref_save_bin(const char *fname, int rows, int cols, int nnz, struct mtx *coo) { save_bin(fname, rows, cols, nnz, coo); }
 void ref_free(void *p) { free(p); }
 void ref_sort_mtx(int nnz, struct mtx *coo) { sort_mtx(nnz, coo, by_row_mtx); }
 void ref_mult_mtx(int rows, int cols, int nnz, struct mtx *coo, double *x, double *y) { mult_mtx(rows, cols, nnz, coo, x, y); }

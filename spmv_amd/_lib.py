@@ -35,6 +35,8 @@ SIGNATURES = {
     "spmv_hip_last_error": (C.c_char_p, []),
     "spmv_hip_load_mtx": (_i, [C.c_char_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_vp)]),
     "spmv_hip_free_coo": (None, [_vp]),
+    "spmv_hip_load_bin": (_i, [C.c_char_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_vp)]),
+    "spmv_hip_save_bin": (_i, [C.c_char_p, _i, _i, _i, _vp]),
     "spmv_hip_sort_coo": (None, [_i, _vp]),
     "spmv_hip_create_csr": (_vp, [_i, _i, _i, _i, _vp, _i, _i, _i]),
     "spmv_hip_create_csr_merge": (_vp, [_i, _i, _i, _vp, _i, _i]),

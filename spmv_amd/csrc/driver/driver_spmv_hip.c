@@ -10,8 +10,8 @@
  * with ":f32" for float storage/accumulation.  Per matrix of LIST the driver
  *   1. estimates the memory need like enought_memory (driver_spmv.c:50-110;
  *      .bin headers are read as binary here -- the reference parses them as text),
- *   2. loads it (.mtx: spmv_hip_load_mtx; .bin: the reference's save_bin layout,
- *      mtx.c:207-247) and insists on a square matrix (driver_spmv.c:176-179),
+ *   2. loads it (.mtx: spmv_hip_load_mtx; .bin: spmv_hip_load_bin, the reference's
+ *      save_bin layout, mtx.c:207-247) and insists on a square matrix (driver_spmv.c:176-179),
  *   3. builds the format on the device,
  *   4. fills x, y with the reference's interleaved rand() sequence and
  *      normalises x (driver_spmv.c:267-273),
@@ -98,22 +98,6 @@ static int enough_memory(const char *path, long *rows, long *cols, long *nnz, un
     return *need_mb < free_mb * 0.95;
 }
 
-/* load_bin with the layout save_bin writes (mtx.c:207-247): int rows, int cols, long nnz, then {int,int,double}. */
-static int load_bin(const char *path, int *rows, int *cols, int *nnz, struct mtx **coo)
-{
-    FILE *f = fopen(path, "rb");
-    if (!f) { fprintf(stderr, "Error opening file: %s\n", path); return 1; }
-    int m, n; long nz;
-    if (fread(&m, sizeof m, 1, f) != 1 || fread(&n, sizeof n, 1, f) != 1 || fread(&nz, sizeof nz, 1, f) != 1 ||
-        nz < 0 || nz > 0x7fffffffL) { fprintf(stderr, "Error reading file: %s\n", path); fclose(f); return 1; }
-    struct mtx *a = (struct mtx *)malloc(sizeof(struct mtx) * (size_t)(nz > 0 ? nz : 1));
-    if (!a) { fprintf(stderr, "Out of memory loading: %s\n", path); fclose(f); return 1; }
-    if (fread(a, sizeof(struct mtx), (size_t)nz, f) != (size_t)nz) { fprintf(stderr, "Error reading file: %s\n", path); free(a); fclose(f); return 1; }
-    fclose(f);
-    *rows = m; *cols = n; *nnz = (int)nz; *coo = a;
-    return 0;
-}
-
 /* COO -> plain CSR arrays on the host, for the creators that take CSR (the reference driver gets them from create_csr, driver_spmv.c:207,243) */
 static void coo_to_csr(int rows, int nnz, const struct mtx *coo, int **rp, int **cj, double **va)
 {
@@ -193,7 +177,7 @@ int main(int argc, char *argv[])
         }
         int rows, columns, nnz;
         struct mtx *coo;
-        if (has_suffix(line, ".bin")) { if (load_bin(line, &rows, &columns, &nnz, &coo)) exit(1); }
+        if (has_suffix(line, ".bin")) { if (spmv_hip_load_bin(line, &rows, &columns, &nnz, &coo)) die("load_bin"); }
         else if (has_suffix(line, ".mtx")) { if (spmv_hip_load_mtx(line, &rows, &columns, &nnz, &coo)) die("load_mtx"); }
         else { printf("Unkown file extension\n"); return 1; }
         if (rows != columns) { printf("Matrix is not square\n"); return 1; }

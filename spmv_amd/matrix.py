@@ -185,8 +185,23 @@ def sort_coo(coo: np.ndarray) -> None:
 
 def load_mtx(path: str):
     """load_mtx (mtx.c:36-137) -> (rows, columns, coo)."""
+    return _load(L.lib().spmv_hip_load_mtx, path)
+
+
+def load_bin(path: str):
+    """load_bin (mtx.c:139-205) -> (rows, columns, coo)."""
+    return _load(L.lib().spmv_hip_load_bin, path)
+
+
+def save_bin(path: str, rows: int, columns: int, coo: np.ndarray) -> None:
+    """save_bin (mtx.c:207-247)."""
+    coo = np.ascontiguousarray(coo, dtype=COO_DTYPE)
+    L.check(L.lib().spmv_hip_save_bin(path.encode(), rows, columns, len(coo), _ptr(coo)))
+
+
+def _load(fn, path: str):
     r, c, n, p = C.c_int(), C.c_int(), C.c_int(), C.c_void_p()
-    L.check(L.lib().spmv_hip_load_mtx(path.encode(), C.byref(r), C.byref(c), C.byref(n), C.byref(p)))
+    L.check(fn(path.encode(), C.byref(r), C.byref(c), C.byref(n), C.byref(p)))
     try:
         buf = (C.c_char * (16 * max(n.value, 1))).from_address(p.value)
         coo = np.frombuffer(buf, dtype=COO_DTYPE, count=n.value).copy()

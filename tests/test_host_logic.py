@@ -117,6 +117,95 @@ def test_load_mtx_errors_where_reference_exits(orc, tmp_path, content, msg):
         load_mtx(str(tmp_path / "missing.mtx"))
 
 
+def _big_mtx(path, n=3000, per_row=40, symmetric=False, seed=11):
+    """~3 MB of entry lines, enough for the loader to split the file over threads (one part per MiB)."""
+    rng = np.random.default_rng(seed)
+    i = np.repeat(np.arange(1, n + 1), per_row)
+    j = rng.integers(1, n + 1, size=len(i))
+    if symmetric:
+        i, j = np.maximum(i, j), np.minimum(i, j)
+    a = rng.standard_normal(len(i))
+    a[::97] = 0.0                                                 # explicit zeros are dropped (mtx.c:118)
+    with open(path, "w") as f:
+        f.write(f"%%MatrixMarket matrix coordinate real {'symmetric' if symmetric else 'general'}\n% big\n")
+        f.write(f"{n} {n} {len(i)}\n")
+        f.write("".join(f"{r} {c} {v!r}  \n" for r, c, v in zip(i.tolist(), j.tolist(), a.tolist())))
+    return len(i)
+
+
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_load_mtx_threads_agree_with_sequential_and_oracle(orc, tmp_path, monkeypatch, symmetric):
+    path = str(tmp_path / "big.mtx")
+    _big_mtx(path, symmetric=symmetric)
+    assert os.path.getsize(path) > (2 << 20)
+    got = {}
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("SPMV_HIP_IO_THREADS", threads)
+        got[threads] = load_mtx(path)
+    orows, ocols, ocoo = orc.load_mtx(path)
+    for rows, cols, coo in got.values():
+        assert (rows, cols) == (orows, ocols)
+        assert coo.tobytes() == ocoo.tobytes()                    # same entries in file order, mirrors after their source
+
+
+def test_load_mtx_irregular_layouts_fall_back_to_token_parsing(orc, tmp_path, monkeypatch):
+    monkeypatch.setenv("SPMV_HIP_IO_THREADS", "4")
+    # entries split over lines, several per line, and trailing lines beyond nnz (fscanf-style readers accept all three)
+    text = "%%MatrixMarket matrix coordinate real general\n3 3 3\n1 1\n 2.0 2 2 3.0\n3\n3 4.0\n1 2 9.0\n"
+    path = str(tmp_path / "odd.mtx")
+    open(path, "w").write(text)
+    rows, cols, coo = load_mtx(path)
+    orows, ocols, ocoo = orc.load_mtx(path)
+    assert (rows, cols) == (orows, ocols) == (3, 3)
+    assert coo.tobytes() == ocoo.tobytes()
+    assert coo["a"].tolist() == [2.0, 3.0, 4.0]                   # the line after the third entry is ignored
+
+
+def test_bin_roundtrip_and_errors(tmp_path):
+    rows, cols, rp, cj, va = G.stencil27(4, 3, 5)
+    coo = G.csr_to_coo_numpy(rows, rp, cj, va)
+    path = str(tmp_path / "m.bin")
+    S.save_bin(path, rows, cols, coo)
+    assert os.path.getsize(path) == 4 + 4 + 8 + 16 * len(coo)    # mtx.c:207-247
+    r2, c2, coo2 = S.load_bin(path)
+    assert (r2, c2) == (rows, cols) and coo2.tobytes() == coo.tobytes()
+    with open(path, "r+b") as f:                                  # truncated payload
+        f.truncate(16 + 16 * (len(coo) - 1) + 3)
+    with pytest.raises(S.SpmvHipError, match="Error reading file"):
+        S.load_bin(path)
+    bad = coo.copy()
+    bad["j"][0] = cols
+    S.save_bin(path, rows, cols, bad)
+    with pytest.raises(S.SpmvHipError, match="out of range"):
+        S.load_bin(path)
+    with pytest.raises(S.SpmvHipError, match="Error opening file"):
+        S.load_bin(str(tmp_path / "missing.bin"))
+    S.save_bin(path, 0, 0, coo[:0])
+    assert S.load_bin(path)[0:2] == (0, 0)
+
+
+def test_bin_files_interchange_with_compiled_reference(tmp_path):
+    """save_bin / load_bin of the compiled reference (mtx.c:139-247) and of the library read each other's files."""
+    import ctypes as C
+    import oracle
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not built")
+    R = oracle.ref()
+    rows, cols, rp, cj, va = G.rmat(8, 6, seed=5)
+    coo = G.csr_to_coo_numpy(rows, rp, cj, va)
+    ours, theirs = str(tmp_path / "ours.bin"), str(tmp_path / "theirs.bin")
+    S.save_bin(ours, rows, cols, coo)
+    R.ref_save_bin(theirs.encode(), rows, cols, len(coo), coo.copy())
+    assert open(ours, "rb").read() == open(theirs, "rb").read()
+    r2, c2, coo2 = S.load_bin(theirs)
+    assert (r2, c2) == (rows, cols) and coo2.tobytes() == coo.tobytes()
+    r, c, n, p = C.c_int(), C.c_int(), C.c_int(), C.c_void_p()
+    R.ref_load_bin(ours.encode(), C.byref(r), C.byref(c), C.byref(n), C.byref(p))
+    back = np.frombuffer((C.c_char * (16 * n.value)).from_address(p.value), dtype=COO_DTYPE, count=n.value).copy()
+    R.ref_free(p)
+    assert (r.value, c.value, n.value) == (rows, cols, len(coo)) and back.tobytes() == coo.tobytes()
+
+
 def test_sort_coo_matches_reference_order(orc):
     rng = np.random.default_rng(4)
     n = 5000
