@@ -26,6 +26,8 @@
 #include <vector>
 
 namespace spmv { void set_error(const char *fmt, ...); void clear_error(); }
+// sort.hip: (row, col) radix sort in HBM; 0 = sorted, non-zero = could not run (array untouched)
+extern "C" int spmv_hip_internal_device_sort_coo(long long nnz, struct mtx *coo);
 
 namespace {
 
@@ -170,7 +172,13 @@ extern "C" {
 void spmv_hip_sort_coo(int nnz, struct mtx *coo)
 {
     auto less = [](const struct mtx &a, const struct mtx &b) { return a.i != b.i ? a.i < b.i : a.j < b.j; };
-    if (nnz > 1 && !std::is_sorted(coo, coo + nnz, less)) std::sort(coo, coo + nnz, less);
+    if (nnz < 2 || std::is_sorted(coo, coo + nnz, less)) return;
+    // large arrays: radix sort in HBM (two PCIe passes of 16 B per entry instead of n log n compares);
+    // the host sort remains for small arrays and when the device path cannot run
+    const char *env = getenv("SPMV_HIP_DEVICE_SORT_MIN");
+    const long threshold = env ? atol(env) : (1L << 20);
+    if (nnz >= threshold && spmv_hip_internal_device_sort_coo(nnz, coo) == 0) return;
+    std::stable_sort(coo, coo + nnz, less);
 }
 
 void spmv_hip_free_coo(struct mtx *coo) { free(coo); }

@@ -357,6 +357,31 @@ def test_bench_loop_is_the_drivers_power_iteration(orc, g):
     assert rel(orc, x_last, x) <= 1e-12
 
 
+def test_large_coo_is_sorted_in_hbm_like_the_host_sort(orc, monkeypatch):
+    """sort_mtx order (mtx.c:9-34) from the device radix sort: same array as the host sort, stable for duplicates."""
+    from spmv_amd.matrix import sort_coo
+    rng = np.random.default_rng(8)
+    n = 300000
+    i = rng.integers(0, 5000, n).astype(np.int32)
+    j = rng.integers(0, 5000, n).astype(np.int32)
+    coo = S.make_coo(i, j, np.arange(n, dtype=np.float64))        # values tag the original position
+    coo[:1000]["j"] = coo[1000:2000]["j"]; coo[:1000]["i"] = coo[1000:2000]["i"]   # duplicates
+    order = np.lexsort((np.arange(n), coo["j"], coo["i"]))        # (i, j), ties by position = stable
+    want = coo[order]
+    host = coo.copy()
+    monkeypatch.setenv("SPMV_HIP_DEVICE_SORT_MIN", str(10 ** 9))
+    sort_coo(host)
+    dev = coo.copy()
+    monkeypatch.setenv("SPMV_HIP_DEVICE_SORT_MIN", "1000")
+    sort_coo(dev)
+    assert host.tobytes() == want.tobytes() and dev.tobytes() == want.tobytes()
+    uniq = coo[np.unique(coo["i"].astype(np.int64) * 5000 + coo["j"], return_index=True)[1]]
+    uniq = uniq[rng.permutation(len(uniq))]
+    mine = uniq.copy()
+    sort_coo(mine)
+    assert mine.tobytes() == orc.sort_coo(uniq).tobytes()          # the reference's qsort order on distinct keys
+
+
 def test_errors_are_reported_not_fatal():
     coo = S.make_coo([0, 1], [0, 5], [1.0, 2.0])
     with pytest.raises(S.SpmvHipError, match="column index"):
