@@ -175,7 +175,11 @@ __global__ __launch_bounds__(kBlock) void csr_vector_kernel(int rows, const int 
 {
     static_assert(R <= G, "the first R lanes of a group store its R rows");
     constexpr int kRowsPerBlock = kBlock / G * R;
-    const unsigned b = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    // the grid is folded into two dimensions (one dimension holds fewer than 2^32 threads)
+    const unsigned nblocks = (unsigned)((rows + kRowsPerBlock - 1) / kRowsPerBlock);
+    const unsigned bid = blockIdx.y * gridDim.x + blockIdx.x;
+    if (bid >= nblocks) return;
+    const unsigned b = xcd_contiguous_block(bid, nblocks);
     const int lane = threadIdx.x % G;
     const int row0 = (int)(b * kRowsPerBlock) + (int)(threadIdx.x / G) * R;
     int ptr[R + 1];
@@ -544,6 +548,14 @@ __global__ __launch_bounds__(kBlock) void scale_kernel(int n, const T *__restric
 
 static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
+// A grid of `blocks` workgroups as (x, y) with x <= 2^22, for kernels whose one-dimensional grid would
+// pass the limit of 2^32 threads per dimension; the kernel flattens it and drops the surplus.
+static dim3 folded_grid(unsigned blocks)
+{
+    const unsigned gx = std::min(std::max(blocks, 1u), 1u << 22);
+    return dim3(gx, (blocks + gx - 1) / gx);
+}
+
 template <typename T> static int launch_csr_vector(const spmv_hip_matrix *m, const T *x, T *y, hipStream_t st)
 {
     const int *rp = m->d_row_ptr, *cj = m->d_col;
@@ -557,7 +569,7 @@ template <typename T> static int launch_csr_vector(const spmv_hip_matrix *m, con
                                      : std::min(kRowsOfVariant[m->variant], m->lanes_per_row);
 #define SPMV_VEC_ONE(G, R)                                                                            \
     case G * 16 + R:                                                                                  \
-        hipLaunchKernelGGL((csr_vector_kernel<T, G, R>), dim3(cdiv(rows, kBlock / G * R)), dim3(kBlock), 0, \
+        hipLaunchKernelGGL((csr_vector_kernel<T, G, R>), folded_grid(cdiv(rows, kBlock / G * R)), dim3(kBlock), 0, \
                            st, rows, rp, cj, va, m->d_row_map, x, y);                                 \
         break;
 #define SPMV_VEC_CASE(G) SPMV_VEC_ONE(G, 1) SPMV_VEC_ONE(G, 2) SPMV_VEC_ONE(G, 4) SPMV_VEC_ONE(G, 8)
