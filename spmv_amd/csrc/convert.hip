@@ -64,40 +64,80 @@ int build_merge_tiles(spmv_hip_matrix *m, hipStream_t st)
 // (the reference's per-chunk local CSR holds exactly those: csr_bal.c:45-59).
 // tile_coord[2t] = first non-empty row whose end lies beyond the tile start,
 // tile_coord[2t+1] = tile start in the non-zero array.
+__global__ void row_nonempty_kernel(int rows, const int *__restrict__ row_ptr, int *__restrict__ flag)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows) flag[r] = row_ptr[r + 1] > row_ptr[r];
+}
+
+// pos = exclusive prefix sum of the non-empty flags: row r is entry pos[r] of the compacted list
+__global__ void compact_rows_kernel(int rows, const int *__restrict__ row_ptr, const int *__restrict__ pos,
+                                    int *__restrict__ id, int *__restrict__ end)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows || row_ptr[r + 1] <= row_ptr[r]) return;
+    id[pos[r]] = r;
+    end[pos[r]] = row_ptr[r + 1];
+}
+
+// tile t starts at non-zero b = t * per_tile: first list entry whose end lies beyond b (upper bound)
+__global__ void bal_partition_kernel(int ntiles, int per_tile, int64_t nnz, int list_len,
+                                     const int *__restrict__ end, int *__restrict__ tile_coord)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > ntiles) return;
+    const int64_t b64 = (int64_t)t * per_tile;
+    const int b = (int)(b64 < nnz ? b64 : nnz);
+    int lo = 0, hi = list_len;
+    while (lo < hi) {
+        int mid = (int)(((int64_t)lo + hi) >> 1);
+        if (end[mid] <= b) lo = mid + 1; else hi = mid;
+    }
+    tile_coord[2 * t] = lo;
+    tile_coord[2 * t + 1] = b;
+}
+
 int build_bal_tiles(spmv_hip_matrix *m, hipStream_t st)
 {
     const int rows = m->rows;
     const int64_t nnz = m->stored;
-    std::vector<int> rp((size_t)rows + 1);
-    SPMV_HIP_TRY(hipMemcpyAsync(rp.data(), m->d_row_ptr, sizeof(int) * ((size_t)rows + 1), hipMemcpyDeviceToHost, st), return 1);
-    SPMV_HIP_TRY(hipStreamSynchronize(st), return 1);
-    std::vector<int> id, end;
-    id.reserve(rows); end.reserve(rows);
-    for (int r = 0; r < rows; r++)
-        if (rp[r + 1] > rp[r]) { id.push_back(r); end.push_back(rp[r + 1]); }
-    m->nz_rows = (int)id.size();
-    m->has_empty_rows = m->nz_rows != rows;
     const int ch = m->items_per_tile;
     m->ntiles = (int)((nnz + ch - 1) / ch);
-    std::vector<int> coord(2 * ((size_t)m->ntiles + 1));
-    for (int t = 0; t <= m->ntiles; t++) {
-        int64_t b = std::min<int64_t>((int64_t)t * ch, nnz);
-        int a = (int)(std::upper_bound(end.begin(), end.end(), (int)b) - end.begin());
-        coord[2 * t] = a;
-        coord[2 * t + 1] = (int)b;
-    }
-    if (dev_alloc(m, &m->d_nzr_id, id.size())) return 1;
-    if (dev_alloc(m, &m->d_nzr_end, end.size())) return 1;
-    if (dev_alloc(m, &m->d_tile_coord, coord.size())) return 1;
-    if (dev_alloc(m, &m->d_row_carry, (size_t)m->ntiles)) return 1;
-    if (dev_alloc(m, (char **)&m->d_val_carry, (size_t)m->ntiles * dtype_size(m->dtype))) return 1;
-    if (!id.empty()) {
-        SPMV_HIP_TRY(hipMemcpyAsync(m->d_nzr_id, id.data(), sizeof(int) * id.size(), hipMemcpyHostToDevice, st), return 1);
-        SPMV_HIP_TRY(hipMemcpyAsync(m->d_nzr_end, end.data(), sizeof(int) * end.size(), hipMemcpyHostToDevice, st), return 1);
-    }
-    SPMV_HIP_TRY(hipMemcpyAsync(m->d_tile_coord, coord.data(), sizeof(int) * coord.size(), hipMemcpyHostToDevice, st), return 1);
-    SPMV_HIP_TRY(hipStreamSynchronize(st), return 1);
-    return 0;
+    int *d_flag = nullptr, *d_pos = nullptr;
+    int rc = 1;
+    do {
+        m->nz_rows = 0;
+        if (rows > 0) {
+            if (dev_alloc<int>(nullptr, &d_flag, (size_t)rows) || dev_alloc<int>(nullptr, &d_pos, (size_t)rows)) break;
+            hipLaunchKernelGGL(row_nonempty_kernel, dim3(cdiv64(rows, 256)), dim3(256), 0, st, rows, m->d_row_ptr, d_flag);
+            SPMV_HIP_TRY(hipGetLastError(), break);
+            if (device_exclusive_scan(d_flag, d_pos, (size_t)rows, st)) break;
+            int last_pos = 0, last_flag = 0;
+            SPMV_HIP_TRY(hipMemcpyAsync(&last_pos, d_pos + rows - 1, sizeof(int), hipMemcpyDeviceToHost, st), break);
+            SPMV_HIP_TRY(hipMemcpyAsync(&last_flag, d_flag + rows - 1, sizeof(int), hipMemcpyDeviceToHost, st), break);
+            SPMV_HIP_TRY(hipStreamSynchronize(st), break);
+            m->nz_rows = last_pos + last_flag;
+        }
+        m->has_empty_rows = m->nz_rows != rows;
+        if (dev_alloc(m, &m->d_nzr_id, (size_t)m->nz_rows)) break;
+        if (dev_alloc(m, &m->d_nzr_end, (size_t)m->nz_rows)) break;
+        if (dev_alloc(m, &m->d_tile_coord, 2 * ((size_t)m->ntiles + 1))) break;
+        if (dev_alloc(m, &m->d_row_carry, (size_t)m->ntiles)) break;
+        if (dev_alloc(m, (char **)&m->d_val_carry, (size_t)m->ntiles * dtype_size(m->dtype))) break;
+        if (rows > 0) {
+            hipLaunchKernelGGL(compact_rows_kernel, dim3(cdiv64(rows, 256)), dim3(256), 0, st, rows, m->d_row_ptr, d_pos,
+                               m->d_nzr_id, m->d_nzr_end);
+            SPMV_HIP_TRY(hipGetLastError(), break);
+        }
+        hipLaunchKernelGGL(bal_partition_kernel, dim3(cdiv64(m->ntiles + 1, 256)), dim3(256), 0, st, m->ntiles, ch, nnz,
+                           m->nz_rows, m->d_nzr_end, m->d_tile_coord);
+        SPMV_HIP_TRY(hipGetLastError(), break);
+        SPMV_HIP_TRY(hipStreamSynchronize(st), break);
+        rc = 0;
+    } while (0);
+    if (d_flag) (void)hipFree(d_flag);
+    if (d_pos) (void)hipFree(d_pos);
+    return rc;
 }
 
 // ---------------------------------------------------------- sliced formats ----
@@ -172,6 +212,61 @@ __global__ __launch_bounds__(256) void slice_fill_kernel(int rows, int height, i
     }
 }
 
+// The same fill for slices of 64 rows, transposed through LDS: one wave per slice takes 16 columns at a
+// time; 16-lane groups read 16 consecutive entries of one row each (contiguous 64/128-byte pieces of the
+// CSR arrays, every line used by one or two back-to-back steps), the tile is parked in LDS, and lane k
+// writes row k's entries, so each store instruction is one full 256/512-byte column of the slice.
+constexpr int kFillCols = 16;
+
+template <typename Tin, typename Tout>
+__global__ __launch_bounds__(kWave) void slice_fill64_kernel(int rows, int nslices, const int *__restrict__ row_ptr,
+                                                             const int *__restrict__ col,
+                                                             const Tin *__restrict__ val,
+                                                             const int *__restrict__ row_order,
+                                                             const int64_t *__restrict__ slice_ptr,
+                                                             int *__restrict__ scol, Tout *__restrict__ sval)
+{
+    constexpr int kStride = kFillCols + 1;                   // odd row stride: conflict-free column reads
+    __shared__ int tcol[kWave * kStride];
+    __shared__ Tout tval[kWave * kStride];
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const int64_t base = slice_ptr[s];
+    const int width = (int)((slice_ptr[s + 1] - base) >> 6);
+    const int r = s * kWave + lane;
+    int beg = 0, len = 0;
+    if (r < rows) {
+        const int src = row_order ? row_order[r] : r;
+        beg = row_ptr[src];
+        len = row_ptr[src + 1] - beg;
+    }
+    const int sub = lane / kFillCols, jj = lane % kFillCols;  // 4 rows per load step, 16 columns each
+    for (int j0 = 0; j0 < width; j0 += kFillCols) {
+        int c[kFillCols];
+        Tin v[kFillCols];
+#pragma unroll
+        for (int i = 0; i < kFillCols; i++) {
+            const int row = 4 * i + sub;
+            const int b = __shfl(beg, row, kWave), l = __shfl(len, row, kWave);
+            const bool live = j0 + jj < l;
+            c[i] = live ? col[b + j0 + jj] : 0;
+            v[i] = live ? val[b + j0 + jj] : (Tin)0;
+        }
+#pragma unroll
+        for (int i = 0; i < kFillCols; i++) {
+            tcol[(4 * i + sub) * kStride + jj] = c[i];
+            tval[(4 * i + sub) * kStride + jj] = (Tout)v[i];
+        }
+        __syncthreads();
+        const int ncols = min(kFillCols, width - j0);
+        for (int k = 0; k < ncols; k++) {
+            const int64_t at = base + (int64_t)(j0 + k) * kWave + lane;
+            scol[at] = tcol[lane * kStride + k];
+            sval[at] = tval[lane * kStride + k];
+        }
+        __syncthreads();
+    }
+}
+
 int build_sliced(spmv_hip_matrix *m, const int *d_row_ptr, const int *d_col, const void *d_val,
                  bool val_is_f64, bool sorted, hipStream_t st)
 {
@@ -224,7 +319,22 @@ int build_sliced(spmv_hip_matrix *m, const int *d_row_ptr, const int *d_col, con
             int64_t lanes = (int64_t)m->nslices * H;
             dim3 grid(cdiv64(lanes, 256)), block(256);
             const bool f32 = m->dtype == SPMV_HIP_F32;
-            if (val_is_f64 && !f32)
+            if (!val_is_f64 && !f32) { set_error("sliced: float CSR values cannot build a double matrix"); break; }
+            if (H == kWave) {
+                const dim3 g64((unsigned)m->nslices), b64(kWave);
+                if (val_is_f64 && !f32)
+                    hipLaunchKernelGGL((slice_fill64_kernel<double, double>), g64, b64, 0, st, rows, m->nslices, d_row_ptr,
+                                       d_col, (const double *)d_val, m->d_row_order, m->d_slice_ptr, m->d_scol,
+                                       (double *)m->d_sval);
+                else if (val_is_f64)
+                    hipLaunchKernelGGL((slice_fill64_kernel<double, float>), g64, b64, 0, st, rows, m->nslices, d_row_ptr,
+                                       d_col, (const double *)d_val, m->d_row_order, m->d_slice_ptr, m->d_scol,
+                                       (float *)m->d_sval);
+                else
+                    hipLaunchKernelGGL((slice_fill64_kernel<float, float>), g64, b64, 0, st, rows, m->nslices, d_row_ptr,
+                                       d_col, (const float *)d_val, m->d_row_order, m->d_slice_ptr, m->d_scol,
+                                       (float *)m->d_sval);
+            } else if (val_is_f64 && !f32)
                 hipLaunchKernelGGL((slice_fill_kernel<double, double>), grid, block, 0, st, rows, H, lanes, d_row_ptr, d_col,
                                    (const double *)d_val, m->d_row_order, m->d_slice_ptr, m->d_scol, (double *)m->d_sval);
             else if (val_is_f64 && f32)

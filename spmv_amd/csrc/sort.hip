@@ -15,6 +15,7 @@
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 namespace spmv {
 
@@ -79,6 +80,21 @@ int device_sort_coo(int64_t nnz, struct mtx *coo)
         if (d_val[b]) (void)hipFree(d_val[b]);
     }
     if (d_coo) (void)hipFree(d_coo);
+    return rc;
+}
+
+// out[i] = in[0] + ... + in[i-1] on `st` (rocPRIM device scan; its temporary storage is freed before return)
+int device_exclusive_scan(const int *d_in, int *d_out, size_t n, hipStream_t st)
+{
+    if (n == 0) return 0;
+    size_t temp_bytes = 0;
+    void *d_temp = nullptr;
+    SPMV_HIP_TRY(rocprim::exclusive_scan(nullptr, temp_bytes, d_in, d_out, 0, n, rocprim::plus<int>(), st), return 1);
+    SPMV_HIP_TRY(hipMalloc(&d_temp, std::max<size_t>(temp_bytes, 16)), return 1);
+    int rc = 0;
+    SPMV_HIP_TRY(rocprim::exclusive_scan(d_temp, temp_bytes, d_in, d_out, 0, n, rocprim::plus<int>(), st), rc = 1);
+    if (!rc) SPMV_HIP_TRY(hipStreamSynchronize(st), rc = 1);
+    (void)hipFree(d_temp);
     return rc;
 }
 
