@@ -96,6 +96,33 @@ def test_c2_stencil_252_sell_properties():
     sell.free(); scalar.free()
 
 
+def test_c3_rmat_scale26_kernels_agree():
+    """The full C3 size (67 108 864 rows, ~1.06e9 nnz): independent kernels against the bit-exact
+    lane-per-row kernel, linearity, and the 64-lanes-per-row launch whose grid must be folded."""
+    rows, cols, rp, cj, va = G.rmat(26, 16, device=DEV)
+    nnz = int(rp[-1])
+    assert rows == 1 << 26 and 1.0e9 < nnz < 2 ** 31
+    g = torch.Generator(device=DEV).manual_seed(17)
+    x = torch.rand(cols, dtype=torch.float64, device=DEV, generator=g) - 0.5
+    z = torch.rand(cols, dtype=torch.float64, device=DEV, generator=g) - 0.5
+    scalar = _dev_matrix(S.CSR_SCALAR, rows, cols, rp, cj, va)
+    y_ref = _mult(scalar, x, rows)
+    scalar.set_option("variant", 11)                                   # another chunk size, non-temporal loads
+    assert torch.equal(_mult(scalar, x, rows), y_ref)
+    scalar.free()
+    for fmt, p0 in [(S.CSR_MERGE, 0), (S.CSR_BAL, 0), (S.CSR_VECTOR, 64), (S.CSR_VECTOR, 0)]:
+        m = _dev_matrix(fmt, rows, cols, rp, cj, va, p0)
+        y = _mult(m, x, rows)
+        assert _rel(y, y_ref) <= 1e-13, (S.FORMAT_NAMES[fmt], p0)
+        if fmt == S.CSR_MERGE:
+            assert _rel(_mult(m, 2.0 * x - 3.0 * z, rows), 2.0 * y - 3.0 * _mult(m, z, rows)) <= 1e-13
+            m.set_option("variant", 1)
+            assert _rel(_mult(m, x, rows), y_ref) <= 1e-13
+        m.free()
+        del y
+        torch.cuda.empty_cache()
+
+
 def test_c3_rmat_scale22_merge_and_balanced(orc):
     rows, cols, rp, cj, va = G.rmat(22, 16, device=DEV)
     lens = (rp[1:] - rp[:-1])
