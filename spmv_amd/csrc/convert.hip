@@ -144,18 +144,52 @@ int build_bal_tiles(spmv_hip_matrix *m, hipStream_t st)
 
 // Stable descending sort of the row lengths inside one sigma window per
 // workgroup (reference radix_sort.c:103-122: LSD radix, larger digit first,
-// ties keep ascending row index).  Rank by counting in LDS: position of row i =
-// #{j : len_j > len_i} + #{j < i : len_j == len_i}.
-__global__ __launch_bounds__(1024) void sell_window_sort_kernel(int rows, int window,
+// ties keep ascending row index).  A bitonic network in LDS on (length, position)
+// keys; windows holding a row of 2^17 entries or more are ranked by counting
+// instead: position of row i = #{j : len_j > len_i} + #{j < i : len_j == len_i}.
+__global__ __launch_bounds__(1024) void sell_window_sort_kernel(int rows, int window, int padded,
                                                                 const int *__restrict__ row_ptr,
                                                                 int *__restrict__ row_order,
                                                                 int *__restrict__ sorted_len)
 {
-    extern __shared__ int lens[];
+    extern __shared__ int lens[];                      // `padded` ints: window rounded up to a power of two
+    __shared__ int longest;
     const int w0 = blockIdx.x * window;
     const int n = min(window, rows - w0);
-    for (int i = threadIdx.x; i < n; i += blockDim.x) lens[i] = row_ptr[w0 + i + 1] - row_ptr[w0 + i];
+    if (threadIdx.x == 0) longest = 0;
     __syncthreads();
+    int mine = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        lens[i] = row_ptr[w0 + i + 1] - row_ptr[w0 + i];
+        mine = max(mine, lens[i]);
+    }
+    atomicMax(&longest, mine);
+    __syncthreads();
+    // Lengths below 2^17 and positions below 2^15 pack into one 32-bit key whose ascending order is
+    // "longer first, then lower row": distinct keys, so a bitonic network gives the stable order.
+    if (longest < (1 << 17)) {
+        unsigned *key = (unsigned *)lens;
+        for (int i = threadIdx.x; i < padded; i += blockDim.x)
+            key[i] = i < n ? ((unsigned)((1 << 17) - 1 - lens[i]) << 15) | (unsigned)i : 0xFFFFFFFFu;
+        __syncthreads();
+        for (int k = 2; k <= padded; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = threadIdx.x; i < padded; i += blockDim.x) {
+                    const int partner = i ^ j;
+                    if (partner > i) {
+                        const unsigned a = key[i], b = key[partner];
+                        const bool up = (i & k) == 0;
+                        if ((a > b) == up) { key[i] = b; key[partner] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        for (int r = threadIdx.x; r < n; r += blockDim.x) {
+            row_order[w0 + r] = w0 + (int)(key[r] & 0x7FFFu);
+            sorted_len[w0 + r] = (1 << 17) - 1 - (int)(key[r] >> 15);
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const int li = lens[i];
         int rank = 0;
@@ -287,11 +321,13 @@ int build_sliced(spmv_hip_matrix *m, const int *d_row_ptr, const int *d_col, con
             if (window > kMaxSigma) { set_error("sell: sorting window %lld exceeds %lld rows", (long long)window, (long long)kMaxSigma); break; }
             if (dev_alloc(m, &m->d_row_order, (size_t)rows)) break;
             if (dev_alloc<int>(nullptr, &d_sorted_len, (size_t)rows)) break;
-            size_t lds = (size_t)window * sizeof(int);
+            int padded = 1;
+            while (padded < window) padded <<= 1;
+            size_t lds = (size_t)padded * sizeof(int);
             SPMV_HIP_TRY(hipFuncSetAttribute((const void *)sell_window_sort_kernel,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), break);
             hipLaunchKernelGGL(sell_window_sort_kernel, dim3(cdiv64(rows, window)), dim3(1024), lds, st, rows,
-                               (int)window, d_row_ptr, m->d_row_order, d_sorted_len);
+                               (int)window, padded, d_row_ptr, m->d_row_order, d_sorted_len);
             SPMV_HIP_TRY(hipGetLastError(), break);
         }
         if (m->nslices > 0) {

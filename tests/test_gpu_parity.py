@@ -157,6 +157,29 @@ def test_sell_layout_and_product(g, sigma):
         assert bits_equal(y, g[f"y_sell_s{sigma}"])
 
 
+def test_sell_window_with_a_very_long_row(orc):
+    """A row of 2^17 entries or more takes the counting path of the window sort: same order as the reference's."""
+    n = (1 << 17) + 640
+    dense = 777
+    i = np.concatenate([np.arange(n), np.full(n, dense)]).astype(np.int32)
+    j = np.concatenate([np.arange(n), np.arange(n)]).astype(np.int32)
+    keep = np.ones(2 * n, bool)
+    keep[n + dense] = False                                        # (dense, dense) only once
+    rng = np.random.default_rng(3)
+    coo = S.make_coo(i[keep], j[keep], rng.standard_normal(int(keep.sum())))
+    S.sort_coo(coo)
+    rp, cj, va = coo_to_csr_host(n, coo)
+    x = rng.standard_normal(n)
+    want = orc.mult_csr_base(rp, cj, va, x)
+    for sigma in (1024, 16384):
+        m = Matrix.sell(n, n, rp, cj, va, S.F64, 64, sigma)
+        ref = orc.sell_from_csr(rp, cj, va, 64, sigma)            # sellcs_format.c:138-201 restated
+        assert bits_equal(m.download(S.ARR_ROW_ORDER), ref["row_order"])
+        assert bits_equal(m.download(S.ARR_SLICE_PTR), ref["slice_ptr"])
+        assert bits_equal(m.mult(x), want)
+        m.free()
+
+
 SLICED_VARIANTS = [1, 2, 3, 4, 9, 10, 11, 12]
 
 
