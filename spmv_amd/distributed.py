@@ -62,6 +62,29 @@ class _HipLocal:
         self.m.mult_dev(x.data_ptr(), y.data_ptr(), torch.cuda.current_stream().cuda_stream)
 
 
+def row_blocks_by_nnz(row_ptr, world: int, snap: int = 1024):
+    """Contiguous row blocks with about nnz/world non-zeros each: block p ends at the first row whose
+    row_ptr reaches (p+1)*nnz/world (the equal-share rule of create_csr_bal, reference
+    src/csr_bal.c:83-85, on rows instead of entries), moved to the nearest multiple of `snap` rows so
+    that SELL sorting windows and slices never straddle two GPUs.  Returns world+1 boundaries."""
+    rows = int(row_ptr.numel()) - 1
+    nnz = int(row_ptr[-1])
+    targets = torch.tensor([nnz * (p + 1) // world for p in range(world - 1)], dtype=row_ptr.dtype, device=row_ptr.device)
+    cuts = torch.searchsorted(row_ptr.contiguous(), targets).cpu().tolist()
+    bounds = [0]
+    for c in cuts:
+        c = int(round(c / snap)) * snap if snap > 1 else int(c)
+        bounds.append(min(max(c, bounds[-1]), rows))
+    bounds.append(rows)
+    return bounds
+
+
+def slice_row_block(row_ptr, col, val, r0: int, r1: int):
+    """CSR of rows [r0, r1) of a global CSR (column indices stay global)."""
+    a, b = int(row_ptr[r0]), int(row_ptr[r1])
+    return (row_ptr[r0:r1 + 1] - row_ptr[r0]).to(torch.int32), col[a:b].clone(), val[a:b].clone()
+
+
 def _csr_select(rows, counts, keep_entry, cj, va):
     """CSR of the entries flagged in keep_entry (row structure given by per-row counts)."""
     row_of = torch.repeat_interleave(torch.arange(rows, device=cj.device), counts)

@@ -61,14 +61,16 @@ def _worker(rank, world, port, exchange, kind, out_q):
             r0, r1 = rank * per, (rank + 1) * per
             rows, cols, rp, cj, va = G.stencil27(nx, ny, nz, row_begin=r0, row_end=r1)
         else:                                   # skewed rows, empty rows, long-range columns
+            from spmv_amd.distributed import row_blocks_by_nnz, slice_row_block
             total = 90 * world
             _, _, rp_f, cj_f, va_f = G.power_law_rows(total, seed=9)
-            per = total // world
-            r0, r1 = rank * per, (rank + 1) * per
-            a, b = int(rp_f[r0]), int(rp_f[r1])
-            rows, cols = per, total
-            rp = (rp_f[r0:r1 + 1] - rp_f[r0]).to(torch.int32)
-            cj, va = cj_f[a:b].clone(), va_f[a:b].clone()
+            if kind == "powerlaw_nnz":          # unequal blocks with equal shares of the non-zeros
+                bounds = row_blocks_by_nnz(rp_f, world, snap=2)
+            else:
+                bounds = [r * (total // world) for r in range(world)] + [total]
+            r0, r1 = bounds[rank], bounds[rank + 1]
+            rows, cols = r1 - r0, total
+            rp, cj, va = slice_row_block(rp_f, cj_f, va_f, r0, r1)
         op = RowBlockSpmv(S.SELL, rows, cols, rp, cj, va, S.F64, 64, 1024, row_begin=r0, exchange=exchange,
                           device=torch.device("cpu"), engine=OracleEngine())
         g = torch.Generator().manual_seed(77)
@@ -88,9 +90,28 @@ def _worker(rank, world, port, exchange, kind, out_q):
         dist.destroy_process_group()
 
 
+def test_row_blocks_by_nnz_balances_and_snaps():
+    from spmv_amd.distributed import row_blocks_by_nnz, slice_row_block
+    rows, cols, rp, cj, va = G.rmat(14, 8, seed=5)
+    nnz = int(rp[-1])
+    for world in (2, 4, 8):
+        b = row_blocks_by_nnz(rp, world, snap=64)
+        assert b[0] == 0 and b[-1] == rows and len(b) == world + 1 and all(x <= y for x, y in zip(b, b[1:]))
+        assert all(x % 64 == 0 for x in b[1:-1])
+        shares = [int(rp[b[p + 1]]) - int(rp[b[p]]) for p in range(world)]
+        longest = int((rp[1:] - rp[:-1]).max())
+        assert max(abs(s - nnz / world) for s in shares) <= 64 * longest        # off by at most one snap of rows
+    rp_b, cj_b, va_b = slice_row_block(rp, cj, va, 128, 640)
+    assert int(rp_b[0]) == 0 and int(rp_b[-1]) == len(cj_b) == int(rp[640]) - int(rp[128])
+    assert torch.equal(cj_b, cj[int(rp[128]):int(rp[640])])
+    # equal shares of the stencil fall on plane boundaries when they can
+    rows, cols, rp, cj, va = G.stencil27(8, 8, 32)
+    assert row_blocks_by_nnz(rp, 2, snap=64) == [0, 1024, 2048]
+
+
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("exchange", ["halo", "allgather"])
-@pytest.mark.parametrize("kind", ["stencil", "powerlaw"])
+@pytest.mark.parametrize("exchange,kind", [("halo", "stencil"), ("allgather", "stencil"), ("halo", "powerlaw"),
+                                           ("allgather", "powerlaw"), ("halo", "powerlaw_nnz")])
 def test_row_block_spmv_matches_single_process(orc, world, exchange, kind):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
