@@ -39,6 +39,7 @@ def parse_args():
                                                            "csr_merge", "csr_bal"])
     ap.add_argument("--matrix", default="stencil27", choices=["stencil27", "laplacian2d", "rmat"])
     ap.add_argument("--size", dest="n", type=int, default=0, help="grid edge (stencil27: 252, laplacian2d: 1000) or R-MAT scale")
+    ap.add_argument("--planes", type=int, default=0, help="N > 1: z-planes per GPU (default: the grid edge)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--sigma", type=int, default=1024)
     ap.add_argument("--p0", type=int, default=0, help="format parameter (lanes per row / tile size / slice height)")
@@ -157,9 +158,10 @@ def main():
             workload = f"stencil27 {n}^3"
         else:
             plane = n * n
-            r0, r1 = rank * n * plane, (rank + 1) * n * plane
-            rows, cols, rp, cj, va = G.stencil27(n, n, n * world, device=dev, row_begin=r0, row_end=r1)
-            workload = f"stencil27 {n}x{n}x{n * world}, z-slab of {n} planes per GPU"
+            nzp = args.planes or n          # BASELINE configs[3] (530^3 over 8 GPUs): --size 530 --planes 66
+            r0, r1 = rank * nzp * plane, (rank + 1) * nzp * plane
+            rows, cols, rp, cj, va = G.stencil27(n, n, nzp * world, device=dev, row_begin=r0, row_end=r1)
+            workload = f"stencil27 {n}x{n}x{nzp * world}, z-slab of {nzp} planes per GPU"
     elif args.matrix == "laplacian2d":
         n = args.n or 1000
         rows, cols, rp, cj, va = G.laplacian2d(n, device=dev)
