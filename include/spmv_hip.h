@@ -204,7 +204,8 @@ int spmv_hip_set_option(spmv_hip_matrix *m, const char *name, int64_t value);
  * zero vector and keeps the fastest.  Variant 0 of the sliced formats keeps
  * mult_csr_base's summation order (bit-identical y); the others reassociate.
  * All CSR_SCALAR variants (LDS chunk sizes) give the same bits.  For CSR_VECTOR
- * the trial covers lanes per row x rows walked side by side per lane group. */
+ * the trial covers lanes per row x rows walked side by side per lane group, and
+ * the LDS-staged kernel for short rows (variants 5, 6). */
 int spmv_hip_analyze(spmv_hip_matrix *m, int reps);
 
 /* ---- introspection for layout-parity tests ---------------------------------- */

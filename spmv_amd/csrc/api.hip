@@ -129,6 +129,8 @@ static int finish_from_device_csr(spmv_hip_matrix *m, int64_t p0, int64_t p1, bo
     case SPMV_HIP_CSR_VECTOR: {
         int g = p0 ? (int)p0 : choose_lanes_per_row(m->rows, m->stored);
         if (g < 2 || g > 64 || (g & (g - 1))) { set_error("lanes_per_row %d must be a power of two in 2..64", g); return 1; }
+        // left to the library, rows averaging fewer than 32 entries take the LDS-staged kernel (variant 5)
+        if (!p0 && g <= 32) { g = std::min(g, 8); m->variant = 5; }
         m->lanes_per_row = g;
         return 0;
     }

@@ -214,6 +214,84 @@ __global__ __launch_bounds__(kBlock) void csr_vector_kernel(int rows, const int 
     if (lane < R && row < rows) y[row_map ? row_map[row] : row] = mine;
 }
 
+// G lanes per row with the stream staged through LDS, for rows much shorter than a wave: the kernel
+// above reads such rows in pieces of G entries, so every 128-byte line is fetched by several
+// instructions one memory round trip apart and half-consumed lines of all resident waves crowd the
+// L2.  Here a 64-lane workgroup owns 64 consecutive rows and walks their contiguous run of the
+// arrays in line-aligned chunks of 64*IPL entries (each line loaded once, by one instruction), parks
+// the products in LDS, and sums them with G lanes per row -- 64/G rows at a time, G passes over the
+// 64 rows -- finishing with the DPP butterfly.  One aligned 64-element store of y per workgroup.
+template <typename T, int IPL, int G, bool NT>
+__global__ __launch_bounds__(kWave) void csr_vector_lds_kernel(int rows, const int *__restrict__ row_ptr,
+                                                               const int *__restrict__ col,
+                                                               const T *__restrict__ val,
+                                                               const int *__restrict__ row_map,
+                                                               const T *__restrict__ x, T *__restrict__ y)
+{
+    constexpr int kCap = kWave * IPL, kRowsPerPass = kWave / G;
+    __shared__ T prod[kCap];
+    const int blk = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int lane = threadIdx.x, sub = lane % G;
+    const int row = blk * kWave + lane;
+    const int last = min(blk * kWave + kWave, rows);
+    const int rs = row_ptr[min(row, rows)];
+    const int re = row < rows ? row_ptr[row + 1] : rs;
+    const int run_begin = __builtin_amdgcn_readfirstlane(rs);
+    const int run_end = row_ptr[last];
+    int beg[G], end[G];                       // the row this lane helps with in pass p: p * 64/G + lane / G
+    T acc[G];
+#pragma unroll
+    for (int p = 0; p < G; p++) {
+        beg[p] = __shfl(rs, p * kRowsPerPass + lane / G, kWave);
+        end[p] = __shfl(re, p * kRowsPerPass + lane / G, kWave);
+        acc[p] = 0;
+    }
+    auto load_chunk = [&](int e0, int (&cc)[IPL], T (&vv)[IPL]) {
+#pragma unroll
+        for (int i = 0; i < IPL; i++) {
+            const int *q = col + min(max(e0 + lane + i * kWave, run_begin), run_end - 1);
+            cc[i] = NT ? __builtin_nontemporal_load(q) : *q;
+        }
+#pragma unroll
+        for (int i = 0; i < IPL; i++) {
+            const T *q = val + min(max(e0 + lane + i * kWave, run_begin), run_end - 1);
+            vv[i] = NT ? __builtin_nontemporal_load(q) : *q;
+        }
+    };
+    int cc[IPL];
+    T vv[IPL];
+    const int first = run_begin & ~31;
+    if (run_begin < run_end) load_chunk(first, cc, vv);
+    for (int e0 = first; e0 < run_end; e0 += kCap) {
+        const int n = min(kCap, run_end - e0);
+        T xx[IPL];
+        int cnext[IPL];
+        T vnext[IPL];
+#pragma unroll
+        for (int i = 0; i < IPL; i++) xx[i] = x[cc[i]];
+        if (e0 + kCap < run_end) load_chunk(e0 + kCap, cnext, vnext);
+#pragma unroll
+        for (int i = 0; i < IPL; i++) prod[lane + i * kWave] = xx[i] * vv[i];
+#pragma unroll
+        for (int i = 0; i < IPL; i++) { cc[i] = cnext[i]; vv[i] = vnext[i]; }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < G; p++) {
+            const int kend = min(end[p], e0 + n) - e0;
+            for (int k = max(beg[p], e0) - e0 + sub; k < kend; k += G) acc[p] += prod[k];
+        }
+        __syncthreads();
+    }
+    // row p * 64/G + g is complete in the lanes of group g after the butterfly: park and store in row order
+#pragma unroll
+    for (int p = 0; p < G; p++) {
+        const T total = group_sum<G>(acc[p]);
+        if (sub == 0) prod[p * kRowsPerPass + lane / G] = total;
+    }
+    __syncthreads();
+    if (row < rows) y[row_map ? row_map[row] : row] = prod[lane];
+}
+
 // ------------------------------------------- sliced formats, slice height 64 --
 // One wave per slice.  Slice storage is column-major (reference
 // sellcs_format.c:174-187, sellp.c:440-452): entry j of row k of the slice sits
@@ -564,6 +642,27 @@ template <typename T> static int launch_csr_vector(const spmv_hip_matrix *m, con
     // rows walked side by side by one lane group: variant 1 -> 1, 2 -> 2, 3 -> 4, 4 -> 8 (never more than
     // the group has lanes); variant 0 -> 4 for groups of 16 lanes and more, else 1 (what measurements favour)
     static const int kRowsOfVariant[] = {0, 1, 2, 4, 8};
+    // variants 5, 6: the LDS-staged kernel for short rows (2, 4 or 8 lanes per row; 6 = non-temporal loads)
+    if (m->variant == 5 || m->variant == 6) {
+        const dim3 grid(cdiv(rows, kWave)), block(kWave);
+        const int g = std::min(m->lanes_per_row, 8);
+#define SPMV_VECLDS(G)                                                                                \
+    case G:                                                                                           \
+        if (m->variant == 5)                                                                          \
+            hipLaunchKernelGGL((csr_vector_lds_kernel<T, 8, G, false>), grid, block, 0, st, rows, rp, cj, va, \
+                               m->d_row_map, x, y);                                                   \
+        else                                                                                          \
+            hipLaunchKernelGGL((csr_vector_lds_kernel<T, 8, G, true>), grid, block, 0, st, rows, rp, cj, va, \
+                               m->d_row_map, x, y);                                                   \
+        return 0;
+        switch (g) {
+            SPMV_VECLDS(2)
+            SPMV_VECLDS(4)
+            SPMV_VECLDS(8)
+        default: set_error("csr_vector: lanes_per_row %d is not one of 2,4,8,16,32,64", m->lanes_per_row); return 1;
+        }
+#undef SPMV_VECLDS
+    }
     if (m->variant < 0 || m->variant > 4) { set_error("csr_vector: unknown kernel variant %d", m->variant); return 1; }
     const int side = m->variant == 0 ? (m->lanes_per_row >= 16 ? 4 : 1)
                                      : std::min(kRowsOfVariant[m->variant], m->lanes_per_row);
@@ -606,6 +705,9 @@ int variant_candidates(const spmv_hip_matrix *m, int *out, int max_out)
         for (int g = 2; g <= 64; g *= 2)
             for (int v = 1; v <= 3; v++)
                 if ((1 << (v - 1)) <= g && n < max_out) out[n++] = g + 256 * v;
+        for (int g = 2; g <= 8; g *= 2)                      // LDS-staged kernel for short rows
+            for (int v = 5; v <= 6; v++)
+                if (n < max_out) out[n++] = g + 256 * v;
     } else if (m->format == SPMV_HIP_CSR_SCALAR) {
         // LDS chunk sizes of the staged lane-per-row kernel (all give the same bits)
         for (int v : {0, 2, 3, 4, 8, 10, 11, 12})
