@@ -124,6 +124,11 @@ static int normalize_tile_param(int64_t p, int dflt, int *out)
 // `csr_val_is_f64` tells the element type of d_val).
 static int finish_from_device_csr(spmv_hip_matrix *m, int64_t p0, int64_t p1, bool csr_val_is_f64, hipStream_t st)
 {
+    // the CSR kernels step through the entry arrays in chunks of up to 2048 with 32-bit positions
+    if (m->stored > 0x7fffffffLL - 4096) {
+        set_error("%lld stored entries: 32-bit CSR positions need 4096 entries of headroom below 2^31", (long long)m->stored);
+        return 1;
+    }
     switch (m->format) {
     case SPMV_HIP_CSR_SCALAR: m->lanes_per_row = 1; return 0;
     case SPMV_HIP_CSR_VECTOR: {
