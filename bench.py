@@ -237,6 +237,28 @@ def main():
     kernel_ms = sorted(s.elapsed_time(e) for s, e in zip(starts, ends))
     mean_kernel_ms = sum(kernel_ms) / len(kernel_ms)
 
+    # outside the timed region: the exchange alone and the local products alone, to say how much of
+    # the communication the overlap hides (max over ranks of per-step means)
+    comm = None
+    if world > 1:
+        def timed_ms(fn, reps=10):
+            fn()
+            torch.cuda.synchronize()
+            dist.barrier()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            t = torch.tensor([a.elapsed_time(b) / reps], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        exchange_ms = timed_ms(op.exchange_only)
+        compute_ms = timed_ms(lambda: op.compute_only(y))
+        comm = {"exchange_alone_ms": round(exchange_ms, 5), "local_products_alone_ms": round(compute_ms, 5),
+                "halo_entries_rank0": int(op.nhalo)}
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         gflops = 2.0 * global_nnz / (ms_per_step * 1e-3) / 1e9
@@ -261,6 +283,9 @@ def main():
                          "algorithmic_bytes_per_launch": b_alg, "kernel_ms_mean": round(mean_kernel_ms, 5),
                          "kernel_ms_min": round(kernel_ms[0], 5), "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 5)},
         }
+        if comm is not None:
+            comm["exposed_ms"] = round(max(ms_per_step - comm["local_products_alone_ms"], 0.0), 5)
+            out["communication"] = comm
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_n)
         print(json.dumps(out), flush=True)

@@ -256,6 +256,26 @@ class RowBlockSpmv:
             self.A_bnd.mult(self.x_ext, y)
         return y
 
+    def exchange_only(self):
+        """The x exchange of one product without the local products (for timing the communication alone)."""
+        if self.A_glob is not None:
+            if self.world > 1 and not self.stage_host:
+                dist.all_gather_into_tensor(self.x_full, self.x_local.contiguous(), group=self.group)
+            return
+        if self.send_index.numel():
+            torch.index_select(self.x_local, 0, self.send_index, out=self.send_buf)
+        self._exchange_halo()
+
+    def compute_only(self, y):
+        """The local products of one product against whatever x / halo values are in place (no exchange)."""
+        if self.A_glob is not None:
+            self.A_glob.mult(self.x_full, y)
+            return y
+        self.A_int.mult(self.x_local, y)
+        if self.A_bnd is not None:
+            self.A_bnd.mult(self.x_ext, y)
+        return y
+
     def norm2(self, v):
         """Global ||v||_2 of a row-partitioned vector (the driver's vec_norm, reference driver_spmv.c:21-26)."""
         s = torch.sum(v.to(torch.float64) ** 2).reshape(1)
