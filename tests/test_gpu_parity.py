@@ -14,6 +14,7 @@ import numpy as np
 import pytest
 
 import spmv_amd as S
+from spmv_amd import generators as G
 from spmv_amd.matrix import Matrix, coo_to_csr_host
 from tests import cases as CS
 from tests.util import bits_equal, coo_of, golden_names, load_golden
@@ -412,6 +413,30 @@ def test_large_coo_is_sorted_in_hbm_like_the_host_sort(orc, monkeypatch):
     mine = uniq.copy()
     sort_coo(mine)
     assert mine.tobytes() == orc.sort_coo(uniq).tobytes()          # the reference's qsort order on distinct keys
+
+
+def test_create_free_cycles_return_all_device_memory():
+    import torch
+    rows, cols, rp, cj, va = G.stencil27(24)
+    coo = G.csr_to_coo_numpy(rows, rp, cj, va)
+    rp, cj, va = rp.numpy(), cj.numpy(), va.numpy()
+    x = np.ones(cols)
+
+    def cycle():
+        for mode in list(S.MODES) + ["auto"]:
+            m = S.create(mode, rows, cols, coo.copy())
+            m.analyze(1)
+            m.mult(x)
+            m.free()
+        with pytest.raises(S.SpmvHipError):                        # failed builds release what they took
+            Matrix.sell(rows, cols, rp, cj, va, S.F64, 64, 100)
+    cycle()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(5):
+        cycle()
+    torch.cuda.synchronize()
+    assert abs(torch.cuda.mem_get_info()[0] - free0) <= (8 << 20)
 
 
 def test_errors_are_reported_not_fatal():
