@@ -46,7 +46,8 @@ enum {
     SPMV_HIP_CSR_BAL    = 3,  /* nnz-balanced tiles, LDS-staged      (mult_csr_bal,   csr_bal.c:3-38) */
     SPMV_HIP_SELL       = 4,  /* SELL-C-sigma                        (mult_sell,      sell.c:35-42)  */
     SPMV_HIP_SELLP      = 5,  /* sliced ELL, natural row order       (mult_sellp,     sellp.c:304-342) */
-    SPMV_HIP_ELL        = 6   /* sliced ELL, natural row order       (mult_ell,       ell.c:28-45)   */
+    SPMV_HIP_ELL        = 6,  /* sliced ELL, natural row order       (mult_ell,       ell.c:28-45)   */
+    SPMV_HIP_SELL_DFC   = 7   /* SELL-C-sigma without padding: active lanes per column (csr_to_sellcs_dfc, sellcs_format.c:53-136) */
 };
 
 /* arrays that spmv_hip_download() can read back (layout parity tests) */
@@ -56,7 +57,9 @@ enum {
     SPMV_HIP_ARR_VAL        = 2,  /* dtype  [stored]            CSR val / sliced values          */
     SPMV_HIP_ARR_SLICE_PTR  = 3,  /* int64  [nslices+1]         sliced formats (slice_pointers / block_ptr) */
     SPMV_HIP_ARR_ROW_ORDER  = 4,  /* int32  [rows]              SELL only (row_order)            */
-    SPMV_HIP_ARR_TILE_COORD = 5   /* int32  [2*(ntiles+1)]      merge: (row,nnz) start of each tile; bal: (compact row, nnz) */
+    SPMV_HIP_ARR_TILE_COORD = 5,  /* int32  [2*(ntiles+1)]      merge: (row,nnz) start of each tile; bal: (compact row, nnz) */
+    SPMV_HIP_ARR_VOP_PTR    = 6,  /* int64  [nslices+1]         SELL_DFC: first column of each slice (vop_pointers) */
+    SPMV_HIP_ARR_VOP_LEN    = 7   /* uint8  [vop_ptr[nslices]]  SELL_DFC: active lanes - 1 of every column (vop_lengths) */
 };
 
 typedef struct spmv_hip_info {
@@ -134,6 +137,15 @@ spmv_hip_matrix *spmv_hip_create_sellp(int rows, int columns, int nnz, const int
  * rule, sellcs_format.c:152-158, does not hold) and at most 32768. */
 spmv_hip_matrix *spmv_hip_create_sell(int rows, int columns, int nnz, const int *row_ptr,
                                       const int *col, const double *A, int dtype, int C, int64_t sigma);
+
+/* SELL-C-sigma without padding (the reference builds this layout with
+ * enable_dfc = 1, sellcs-spmv.h:86-98, sellcs_format.c:53-136, but ships no CPU
+ * kernel for it): rows sorted as for SELL; column v of a slice stores only its
+ * active lanes, i.e. the rows of the slice longer than v, which form a prefix
+ * of the slice; `stored` == nnz.  The product keeps mult_csr_base's summation
+ * order.  C must be 64 (one wave per slice); sigma as for SELL. */
+spmv_hip_matrix *spmv_hip_create_sell_dfc(int rows, int columns, int nnz, const int *row_ptr,
+                                          const int *col, const double *A, int dtype, int C, int64_t sigma);
 
 /* ---- creator from CSR arrays already resident in HBM ------------------------
  * For matrices generated on the device.  d_val is float or double per `dtype`.

@@ -25,6 +25,7 @@ assert COO_DTYPE.itemsize == 16
 _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
 _i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 _coop = np.ctypeslib.ndpointer(COO_DTYPE, flags="C_CONTIGUOUS")
 
@@ -69,6 +70,9 @@ def lib():
         "orc_sell_fill": (None, [C.c_int, C.c_int, _i32p, _i32p, _f64p, _i32p, _i64p, C.c_int64,
                                  _i32p, _f64p]),
         "orc_mult_sell": (None, [C.c_int, C.c_int, _i32p, _i64p, _i32p, _i32p, _f64p, _f64p, _f64p]),
+        "orc_sell_dfc": (C.c_int64, [C.c_int, C.c_int, _i32p, _i32p, _i32p, _f64p, _i32p, _i32p, _i64p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+        "orc_mult_sell_dfc": (None, [C.c_int, C.c_int, _i32p, _i64p, _u8p, _i64p, _i32p, _i32p, _f64p, _f64p, _f64p]),
         "orc_sliced_ell_blocks": (C.c_int64, [C.c_int, C.c_int, _i32p, _i64p]),
         "orc_sliced_ell_fill": (None, [C.c_int, C.c_int, _i32p, _i32p, _f64p, _i64p, _i32p, _f64p]),
         "orc_mult_sliced_ell": (None, [C.c_int, C.c_int, _i64p, _i32p, _f64p, _f64p, _f64p]),
@@ -184,6 +188,37 @@ def sell_from_csr(rp, cj, va, C_=64, sigma=16384):
                 C=C_, sigma=sigma, nrows=n)
 
 
+def sell_dfc_from_csr(rp, cj, va, C_=64, sigma=16384):
+    """SELL-C-sigma without padding (sellcs_format.c:53-136): dict(row_order, slice_widths, vop_ptr, vop_len,
+    slice_ptr, col, val)."""
+    L = lib()
+    n = len(rp) - 1
+    rs = np.ascontiguousarray(np.empty(max(n, 1), np.int32)[:n]); ro = np.ascontiguousarray(np.empty(max(n, 1), np.int32)[:n])
+    L.orc_sell_row_order(n, rp, sigma, rs, ro)
+    ns = (n + C_ - 1) // C_
+    sw = np.zeros(max(ns, 1), np.int32)[:ns]; vp = np.zeros(ns + 1, np.int64)
+    sw = np.ascontiguousarray(sw)
+    vops = L.orc_sell_dfc(n, C_, rs, rp, cj, va, ro, sw, vp, None, None, None, None)
+    vl = np.zeros(max(vops, 1), np.uint8); sp = np.zeros(ns + 1, np.int64)
+    nnz = int(rp[-1])
+    dc = np.zeros(max(nnz, 1), np.int32); dv = np.zeros(max(nnz, 1), np.float64)
+    total = L.orc_sell_dfc(n, C_, rs, rp, cj, va, ro, sw, vp, vl.ctypes.data, sp.ctypes.data, dc.ctypes.data,
+                           dv.ctypes.data)
+    assert total == nnz
+    return dict(row_order=ro, slice_widths=sw, vop_ptr=vp, vop_len=vl[:vops], slice_ptr=sp, col=dc[:nnz], val=dv[:nnz],
+                rows_size_sorted=rs, C=C_, sigma=sigma, nrows=n)
+
+
+def mult_sell_dfc(D, x):
+    y = np.zeros(D["nrows"], np.float64)
+    vl = D["vop_len"] if len(D["vop_len"]) else np.zeros(1, np.uint8)
+    dc = D["col"] if len(D["col"]) else np.zeros(1, np.int32)
+    dv = D["val"] if len(D["val"]) else np.zeros(1, np.float64)
+    lib().orc_mult_sell_dfc(D["nrows"], D["C"], D["slice_widths"], D["vop_ptr"], np.ascontiguousarray(vl), D["slice_ptr"],
+                            D["row_order"], np.ascontiguousarray(dc), np.ascontiguousarray(dv), x, y)
+    return y
+
+
 def mult_sell(S, x):
     y = np.zeros(S["nrows"], np.float64)
     lib().orc_mult_sell(S["nrows"], S["C"], S["slice_widths"], S["slice_ptr"], S["row_order"],
@@ -286,6 +321,9 @@ def ref():
         "ref_sell_slice_widths": (C.POINTER(ci), [vp]),
         "ref_sell_slice_pointers": (C.POINTER(ci), [vp]),
         "ref_sell_row_order": (C.POINTER(ci), [vp]),
+        "ref_create_sell_dfc": (vp, [C.POINTER(_CSR), ci, C.c_uint64]),
+        "ref_sell_vop_lengths": (C.POINTER(C.c_uint8), [vp]),
+        "ref_sell_vop_pointers": (C.POINTER(C.c_uint64), [vp]),
         "ref_sell_column_indices": (C.POINTER(ci), [vp]),
         "ref_sell_values": (C.POINTER(C.c_double), [vp]),
         "ref_sell_shift": (ci, [vp]),

@@ -81,6 +81,17 @@ int      *ref_sell_column_indices(void *m) { return ((sellcs_matrix_t *)m)->colu
 double   *ref_sell_values(void *m)         { return ((sellcs_matrix_t *)m)->values; }
 int       ref_sell_shift(void *m)          { return ((sellcs_matrix_t *)m)->shift; }
 void      ref_free_sell(void *m)           { free_sellcs((sellcs_matrix_t *)m); free(m); }
+// the same conversion with enable_dfc = 1 (sellcs_format.c:203-225 -> csr_to_sellcs_dfc :53-136); the
+// handle is a zero-initialised sellcs_matrix_t that the tests read through the accessors and never free
+void *ref_create_sell_dfc(struct csr *c, int C, uint64_t sigma)
+{
+    sellcs_matrix_t *m = (sellcs_matrix_t *)calloc(1, sizeof(sellcs_matrix_t));
+    sellcs_init_params(C, sigma, m);
+    sellcs_create_matrix_from_CSR_rd(c->rows, c->columns, c->i, (const index_t *)c->j, c->A, 0, 1, m);
+    return m;
+}
+unsigned char      *ref_sell_vop_lengths(void *m)  { return ((sellcs_matrix_t *)m)->vop_lengths; }
+unsigned long long *ref_sell_vop_pointers(void *m) { return (unsigned long long *)((sellcs_matrix_t *)m)->vop_pointers; }
 
 // ---- SELLP (sellp.c) ----
 struct sellp *ref_create_sellp(int rows, int cols, int nnz, const int *row_ptr, const int *col, const double *A) { return create_sellp(rows, cols, nnz, row_ptr, col, A); }

@@ -331,6 +331,78 @@ void orc_sell_fill(int nrows, int C, const int *row_ptr, const int *col, const d
     }
 }
 
+/* sellcs_format.c:53-136, sellcs_utils.c:79-125 */
+int64_t orc_sell_dfc(int nrows, int C, const int *rows_size_sorted, const int *row_ptr, const int *col,
+                     const double *val, const int *row_order, int *slice_widths, int64_t *vop_ptr,
+                     unsigned char *vop_len, int64_t *slice_ptr, int *dfc_col, double *dfc_val)
+{
+    int nslices = (nrows + C - 1) / C;
+    int64_t vops = 0;
+    for (int s = 0; s < nslices; s++) {              /* sellcs_format.c:66-76 */
+        slice_widths[s] = rows_size_sorted[s * C];
+        vop_ptr[s] = vops;
+        vops += rows_size_sorted[s * C];
+    }
+    vop_ptr[nslices] = vops;
+    if (!vop_len) return vops;
+    /* sellcs_utils.c:79-125: walk each slice from its shortest row up; every time the row size
+     * grows by d, d more columns exist with the lanes of the shorter rows switched off */
+    int64_t at = 0;
+    for (int i = 0; i < nrows; i += C) {
+        int last_row = i + C > nrows ? nrows - 1 : i + C - 1;
+        int64_t prev = 0;
+        int to_disable = 0;
+        int lanes = last_row - i;                     /* active lanes - 1 */
+        for (int j = last_row; j >= i; j--) {
+            int64_t cur = rows_size_sorted[j];
+            int64_t diff = cur - prev;
+            if (diff > 0) {
+                lanes -= to_disable;
+                for (int64_t k = 0; k < diff; k++) vop_len[at++] = (unsigned char)lanes;
+                to_disable = 1;
+                prev = cur;
+            } else {
+                to_disable++;
+            }
+        }
+    }
+    /* sellcs_format.c:88-98 entry offsets, :109-127 fill */
+    int64_t size = 0, v = 0;
+    for (int s = 0; s < nslices; s++) {
+        slice_ptr[s] = size;
+        for (int w = 0; w < slice_widths[s]; w++) size += vop_len[v++] + 1;
+    }
+    slice_ptr[nslices] = size;
+    for (int s = 0; s < nslices; s++) {
+        int64_t ins = slice_ptr[s], vid = vop_ptr[s];
+        for (int w = 0; w < slice_widths[s]; w++, vid++)
+            for (int r = 0; r < vop_len[vid] + 1; r++) {
+                int64_t src = row_ptr[row_order[s * C + r]] + w;
+                dfc_val[ins] = val[src]; dfc_col[ins] = col[src];
+                ins++;
+            }
+    }
+    return size;
+}
+
+void orc_mult_sell_dfc(int nrows, int C, const int *slice_widths, const int64_t *vop_ptr,
+                       const unsigned char *vop_len, const int64_t *slice_ptr, const int *row_order,
+                       const int *dfc_col, const double *dfc_val, const double *x, double *y)
+{
+    int nslices = (nrows + C - 1) / C;
+    for (int r = 0; r < nrows; r++) y[r] = 0.0;
+    for (int s = 0; s < nslices; s++) {
+        int64_t at = slice_ptr[s];
+        for (int w = 0; w < slice_widths[s]; w++) {
+            int active = vop_len[vop_ptr[s] + w] + 1;
+            for (int k = 0; k < active; k++, at++) {
+                int row = row_order[s * C + k];
+                y[row] = fma(x[dfc_col[at]], dfc_val[at], y[row]);
+            }
+        }
+    }
+}
+
 /* sellcs_mv_autovector.c:19-55 */
 void orc_mult_sell(int nrows, int C, const int *slice_widths, const int64_t *slice_ptr,
                    const int *row_order, const int *sell_col, const double *sell_val,

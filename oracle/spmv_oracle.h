@@ -85,6 +85,22 @@ int64_t orc_sell_slices(int nrows, int C, const int *rows_size_sorted,
 void orc_sell_fill(int nrows, int C, const int *row_ptr, const int *col, const double *val,
                    const int *row_order, const int64_t *slice_ptr, int64_t padded,
                    int *sell_col, double *sell_val);
+/* SELL-C-sigma without padding ("DFC": every column of a slice stores only its
+ * active lanes, a prefix of the slice because its rows are sorted by length).
+ * sellcs_format.c:53-136 with sellcs_set_active_lanes, sellcs_utils.c:79-125.
+ * Pass 1 (vop_len == NULL): fills slice_widths[nslices], vop_ptr[nslices+1]
+ * and returns the number of columns ("vops").  Pass 2: fills vop_len[vops]
+ * (active lanes - 1), slice_ptr[nslices+1] (entry offsets), dfc_col / dfc_val
+ * (exactly nnz entries) and returns the entry count. */
+int64_t orc_sell_dfc(int nrows, int C, const int *rows_size_sorted, const int *row_ptr, const int *col,
+                     const double *val, const int *row_order, int *slice_widths, int64_t *vop_ptr,
+                     unsigned char *vop_len, int64_t *slice_ptr, int *dfc_col, double *dfc_val);
+/* y = A x from the DFC layout: column by column, active lanes only; each row's
+ * entries are added in ascending position with one fma (the reference ships no
+ * DFC product for CPUs; the order is that of mult_csr_base, csr.c:4-13). */
+void orc_mult_sell_dfc(int nrows, int C, const int *slice_widths, const int64_t *vop_ptr,
+                       const unsigned char *vop_len, const int64_t *slice_ptr, const int *row_order,
+                       const int *dfc_col, const double *dfc_val, const double *x, double *y);
 /* sellcs_mv_autovector.c:19-55  accumulates into y (caller zeroes it); lanes
  * past nrows are skipped (the reference reads uninitialised row_order there). */
 void orc_mult_sell(int nrows, int C, const int *slice_widths, const int64_t *slice_ptr,

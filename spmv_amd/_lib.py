@@ -13,11 +13,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspmv_hip.so")
 
 F64, F32 = 0, 1
-CSR_SCALAR, CSR_VECTOR, CSR_MERGE, CSR_BAL, SELL, SELLP, ELL = range(7)
-ARR_ROW_PTR, ARR_COL, ARR_VAL, ARR_SLICE_PTR, ARR_ROW_ORDER, ARR_TILE_COORD = range(6)
+CSR_SCALAR, CSR_VECTOR, CSR_MERGE, CSR_BAL, SELL, SELLP, ELL, SELL_DFC = range(8)
+ARR_ROW_PTR, ARR_COL, ARR_VAL, ARR_SLICE_PTR, ARR_ROW_ORDER, ARR_TILE_COORD, ARR_VOP_PTR, ARR_VOP_LEN = range(8)
 
 FORMAT_NAMES = {CSR_SCALAR: "csr_scalar", CSR_VECTOR: "csr_vector", CSR_MERGE: "csr_merge",
-                CSR_BAL: "csr_bal", SELL: "sell", SELLP: "sellp", ELL: "ell"}
+                CSR_BAL: "csr_bal", SELL: "sell", SELLP: "sellp", ELL: "ell", SELL_DFC: "sell_dfc"}
 
 
 class Info(C.Structure):
@@ -44,6 +44,7 @@ SIGNATURES = {
     "spmv_hip_create_ell": (_vp, [_i, _i, _i, _vp, _i, _i]),
     "spmv_hip_create_sellp": (_vp, [_i, _i, _i, _vp, _vp, _vp, _i, _i]),
     "spmv_hip_create_sell": (_vp, [_i, _i, _i, _vp, _vp, _vp, _i, _i, _i64]),
+    "spmv_hip_create_sell_dfc": (_vp, [_i, _i, _i, _vp, _vp, _vp, _i, _i, _i64]),
     "spmv_hip_create_from_device_csr": (_vp, [_i, _i, _i, _i64, _vp, _vp, _vp, _i, _i64, _i64, _vp]),
     "spmv_hip_create_auto": (_vp, [_i, _i, _i, _vp, _i, _i]),
     "spmv_hip_create_auto_from_device_csr": (_vp, [_i, _i, _i64, _vp, _vp, _vp, _i, _i, _vp]),

@@ -161,6 +161,18 @@ static int finish_from_device_csr(spmv_hip_matrix *m, int64_t p0, int64_t p1, bo
         m->device_bytes -= csr_bytes;
         return rc;
     }
+    case SPMV_HIP_SELL_DFC: {
+        m->slice_height = p0 ? (int)p0 : kDefaultC;
+        m->sigma = p1 ? p1 : kDefaultSigma;
+        if (m->sigma < 1) { set_error("sigma must be positive"); return 1; }
+        const int *rp = m->d_row_ptr, *cj = m->d_col;
+        const void *va = m->d_val;
+        int64_t csr_bytes = m->owns_csr ? m->device_bytes : 0;
+        int rc = build_sell_dfc(m, rp, cj, va, csr_val_is_f64, st);
+        release_csr(m);
+        m->device_bytes -= csr_bytes;
+        return rc;
+    }
     default: set_error("unknown format %d", m->format); return 1;
     }
 }
@@ -172,7 +184,8 @@ static spmv_hip_matrix *create_from_host_csr(int format, int rows, int columns, 
     if (check_columns(columns, cj)) return nullptr;
     spmv_hip_matrix *m = new_handle(format, dtype, rows, columns, nnz);
     if (!m) return nullptr;
-    const bool sliced = format == SPMV_HIP_SELL || format == SPMV_HIP_SELLP || format == SPMV_HIP_ELL;
+    const bool sliced = format == SPMV_HIP_SELL || format == SPMV_HIP_SELLP || format == SPMV_HIP_ELL ||
+                        format == SPMV_HIP_SELL_DFC;
     if (upload_csr(m, rp, cj, va, /*keep_f64_values=*/sliced) || finish_from_device_csr(m, p0, p1, sliced || dtype == SPMV_HIP_F64, nullptr)) {
         spmv_hip_free(m);
         return nullptr;
@@ -293,6 +306,12 @@ spmv_hip_matrix *spmv_hip_create_sell(int rows, int columns, int nnz, const int 
     return create_from_csr_arrays(SPMV_HIP_SELL, rows, columns, nnz, row_ptr, col, A, dtype, C, sigma);
 }
 
+spmv_hip_matrix *spmv_hip_create_sell_dfc(int rows, int columns, int nnz, const int *row_ptr, const int *col,
+                                          const double *A, int dtype, int C, int64_t sigma)
+{
+    return create_from_csr_arrays(SPMV_HIP_SELL_DFC, rows, columns, nnz, row_ptr, col, A, dtype, C, sigma);
+}
+
 spmv_hip_matrix *spmv_hip_create_from_device_csr(int format, int rows, int columns, int64_t nnz, const int *d_row_ptr,
                                                  const int *d_col, const void *d_val, int dtype, int64_t p0, int64_t p1,
                                                  void *stream)
@@ -338,7 +357,8 @@ int spmv_hip_free(spmv_hip_matrix *m)
     if (!m) return 0;
     release_csr(m);
     void *ptrs[] = {m->d_tile_coord, m->d_row_carry, m->d_val_carry, m->d_nzr_id, m->d_nzr_end, m->d_slice_ptr,
-                    m->d_row_order, m->d_scol, m->d_sval, m->d_x, m->d_y, m->d_norm};
+                    m->d_row_order, m->d_scol, m->d_sval, m->d_sorted_len, m->d_vop_ptr, m->d_vop_len,
+                    m->d_x, m->d_y, m->d_norm};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete m;
@@ -576,6 +596,8 @@ int spmv_hip_download(const spmv_hip_matrix *m, int which, void *host, size_t by
     case SPMV_HIP_ARR_SLICE_PTR: src = m->d_slice_ptr; need = sizeof(int64_t) * ((size_t)m->nslices + 1); break;
     case SPMV_HIP_ARR_ROW_ORDER: src = m->d_row_order; need = sizeof(int) * (size_t)m->rows; break;
     case SPMV_HIP_ARR_TILE_COORD: src = m->d_tile_coord; need = sizeof(int) * 2 * ((size_t)m->ntiles + 1); break;
+    case SPMV_HIP_ARR_VOP_PTR: src = m->d_vop_ptr; need = sizeof(int64_t) * ((size_t)m->nslices + 1); break;
+    case SPMV_HIP_ARR_VOP_LEN: src = m->d_vop_len; need = (size_t)m->vops; break;
     default: set_error("unknown array id %d", which); return 1;
     }
     if (!src) { set_error("array %d is not part of format %d", which, m->format); return 1; }

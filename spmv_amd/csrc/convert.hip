@@ -301,6 +301,164 @@ __global__ __launch_bounds__(kWave) void slice_fill64_kernel(int rows, int nslic
     }
 }
 
+// ------------------------------------------- SELL-C-sigma without padding ----
+// Layout of the reference's csr_to_sellcs_dfc (sellcs_format.c:53-136): rows sorted as for SELL; column
+// ("vop") v of a slice stores one entry for every row of the slice longer than v -- a prefix of the slice,
+// as its rows are sorted -- and vop_len holds that count minus one (sellcs_utils.c:79-125).
+
+// one thread per slice: its width (longest = first row) and its number of entries
+__global__ void dfc_slice_stats_kernel(int rows, int nslices, const int *__restrict__ sorted_len,
+                                       int *__restrict__ width, int *__restrict__ entries)
+{
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nslices) return;
+    const int r0 = s * kWave, r1 = min(r0 + kWave, rows);
+    int total = 0;
+    for (int r = r0; r < r1; r++) total += sorted_len[r];
+    width[s] = sorted_len[r0];
+    entries[s] = total;
+}
+
+// one wave per slice: active lanes - 1 of each of its columns
+__global__ __launch_bounds__(kWave) void dfc_vop_len_kernel(int rows, const int *__restrict__ sorted_len,
+                                                            const int64_t *__restrict__ vop_ptr,
+                                                            uint8_t *__restrict__ vop_len)
+{
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const int r = s * kWave + lane;
+    const int len = r < rows ? sorted_len[r] : 0;
+    const int64_t v0 = vop_ptr[s];
+    const int width = (int)(vop_ptr[s + 1] - v0);
+    for (int v = lane; v - lane < width; v += kWave) {
+        int active = 0;
+        for (int k = 0; k < kWave; k++) active += __shfl(len, k, kWave) > v;
+        if (v < width) vop_len[v0 + v] = (uint8_t)(active - 1);
+    }
+}
+
+// one wave per slice: 16 columns at a time through LDS (as slice_fill64_kernel), each column written as the
+// contiguous run of its active lanes
+template <typename Tin, typename Tout>
+__global__ __launch_bounds__(kWave) void dfc_fill_kernel(int rows, const int *__restrict__ row_ptr,
+                                                         const int *__restrict__ col, const Tin *__restrict__ val,
+                                                         const int *__restrict__ row_order,
+                                                         const int *__restrict__ sorted_len,
+                                                         const int64_t *__restrict__ slice_ptr,
+                                                         int *__restrict__ scol, Tout *__restrict__ sval)
+{
+    constexpr int kStride = kFillCols + 1;
+    __shared__ int tcol[kWave * kStride];
+    __shared__ Tout tval[kWave * kStride];
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const int r = s * kWave + lane;
+    int beg = 0, len = 0;
+    if (r < rows) { beg = row_ptr[row_order[r]]; len = sorted_len[r]; }
+    const int width = __shfl(len, 0, kWave);
+    int64_t at = slice_ptr[s];
+    const int sub = lane / kFillCols, jj = lane % kFillCols;
+    for (int j0 = 0; j0 < width; j0 += kFillCols) {
+        int c[kFillCols];
+        Tin v[kFillCols];
+#pragma unroll
+        for (int i = 0; i < kFillCols; i++) {
+            const int row = 4 * i + sub;
+            const int b = __shfl(beg, row, kWave), l = __shfl(len, row, kWave);
+            const bool live = j0 + jj < l;
+            c[i] = live ? col[b + j0 + jj] : 0;
+            v[i] = live ? val[b + j0 + jj] : (Tin)0;
+        }
+#pragma unroll
+        for (int i = 0; i < kFillCols; i++) {
+            tcol[(4 * i + sub) * kStride + jj] = c[i];
+            tval[(4 * i + sub) * kStride + jj] = (Tout)v[i];
+        }
+        __syncthreads();
+        const int ncols = min(kFillCols, width - j0);
+        for (int k = 0; k < ncols; k++) {
+            const bool live = j0 + k < len;
+            if (live) {
+                scol[at + lane] = tcol[lane * kStride + k];
+                sval[at + lane] = tval[lane * kStride + k];
+            }
+            at += __popcll(__ballot(live));
+        }
+        __syncthreads();
+    }
+}
+
+int build_sell_dfc(spmv_hip_matrix *m, const int *d_row_ptr, const int *d_col, const void *d_val,
+                   bool val_is_f64, hipStream_t st)
+{
+    const int rows = m->rows;
+    if (m->slice_height != kWave) { set_error("sell_dfc: C %d must be 64 (one wave per slice)", m->slice_height); return 1; }
+    m->nslices = (rows + kWave - 1) / kWave;
+    const bool f32 = m->dtype == SPMV_HIP_F32;
+    if (!val_is_f64 && !f32) { set_error("sell_dfc: float CSR values cannot build a double matrix"); return 1; }
+    int *d_width = nullptr, *d_entries = nullptr;
+    int rc = 1;
+    std::vector<int> width((size_t)m->nslices), entries((size_t)m->nslices);
+    std::vector<int64_t> vp((size_t)m->nslices + 1), sp((size_t)m->nslices + 1);
+    do {
+        if (dev_alloc(m, &m->d_row_order, (size_t)rows) || dev_alloc(m, &m->d_sorted_len, (size_t)rows)) break;
+        if (rows > 0) {
+            const int64_t window = std::min<int64_t>(m->sigma, rows);
+            if (m->sigma % kWave != 0 && m->sigma < rows) {
+                set_error("sell_dfc: sigma %lld must be a multiple of C 64", (long long)m->sigma);
+                break;
+            }
+            if (window > kMaxSigma) { set_error("sell_dfc: sorting window %lld exceeds %lld rows", (long long)window, (long long)kMaxSigma); break; }
+            int padded = 1;
+            while (padded < window) padded <<= 1;
+            const size_t lds = (size_t)padded * sizeof(int);
+            SPMV_HIP_TRY(hipFuncSetAttribute((const void *)sell_window_sort_kernel,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), break);
+            hipLaunchKernelGGL(sell_window_sort_kernel, dim3(cdiv64(rows, window)), dim3(1024), lds, st, rows,
+                               (int)window, padded, d_row_ptr, m->d_row_order, m->d_sorted_len);
+            SPMV_HIP_TRY(hipGetLastError(), break);
+            if (dev_alloc<int>(nullptr, &d_width, (size_t)m->nslices) || dev_alloc<int>(nullptr, &d_entries, (size_t)m->nslices)) break;
+            hipLaunchKernelGGL(dfc_slice_stats_kernel, dim3(cdiv64(m->nslices, 256)), dim3(256), 0, st, rows, m->nslices,
+                               m->d_sorted_len, d_width, d_entries);
+            SPMV_HIP_TRY(hipGetLastError(), break);
+            SPMV_HIP_TRY(hipMemcpyAsync(width.data(), d_width, sizeof(int) * width.size(), hipMemcpyDeviceToHost, st), break);
+            SPMV_HIP_TRY(hipMemcpyAsync(entries.data(), d_entries, sizeof(int) * entries.size(), hipMemcpyDeviceToHost, st), break);
+        }
+        SPMV_HIP_TRY(hipStreamSynchronize(st), break);
+        int64_t vops = 0, total = 0;
+        for (int s = 0; s < m->nslices; s++) { vp[s] = vops; sp[s] = total; vops += width[s]; total += entries[s]; }
+        vp[m->nslices] = vops; sp[m->nslices] = total;
+        m->vops = vops;
+        m->stored = total;
+        if (dev_alloc(m, &m->d_vop_ptr, vp.size()) || dev_alloc(m, &m->d_slice_ptr, sp.size())) break;
+        if (dev_alloc(m, &m->d_vop_len, (size_t)vops)) break;
+        if (dev_alloc(m, &m->d_scol, (size_t)total)) break;
+        if (dev_alloc(m, (char **)&m->d_sval, (size_t)total * dtype_size(m->dtype))) break;
+        SPMV_HIP_TRY(hipMemcpyAsync(m->d_vop_ptr, vp.data(), sizeof(int64_t) * vp.size(), hipMemcpyHostToDevice, st), break);
+        SPMV_HIP_TRY(hipMemcpyAsync(m->d_slice_ptr, sp.data(), sizeof(int64_t) * sp.size(), hipMemcpyHostToDevice, st), break);
+        if (m->nslices > 0) {
+            const dim3 grid((unsigned)m->nslices), block(kWave);
+            hipLaunchKernelGGL(dfc_vop_len_kernel, grid, block, 0, st, rows, m->d_sorted_len, m->d_vop_ptr, m->d_vop_len);
+            if (val_is_f64 && !f32)
+                hipLaunchKernelGGL((dfc_fill_kernel<double, double>), grid, block, 0, st, rows, d_row_ptr, d_col,
+                                   (const double *)d_val, m->d_row_order, m->d_sorted_len, m->d_slice_ptr, m->d_scol,
+                                   (double *)m->d_sval);
+            else if (val_is_f64)
+                hipLaunchKernelGGL((dfc_fill_kernel<double, float>), grid, block, 0, st, rows, d_row_ptr, d_col,
+                                   (const double *)d_val, m->d_row_order, m->d_sorted_len, m->d_slice_ptr, m->d_scol,
+                                   (float *)m->d_sval);
+            else
+                hipLaunchKernelGGL((dfc_fill_kernel<float, float>), grid, block, 0, st, rows, d_row_ptr, d_col,
+                                   (const float *)d_val, m->d_row_order, m->d_sorted_len, m->d_slice_ptr, m->d_scol,
+                                   (float *)m->d_sval);
+            SPMV_HIP_TRY(hipGetLastError(), break);
+        }
+        SPMV_HIP_TRY(hipStreamSynchronize(st), break);
+        rc = 0;
+    } while (0);
+    if (d_width) (void)hipFree(d_width);
+    if (d_entries) (void)hipFree(d_entries);
+    return rc;
+}
+
 int build_sliced(spmv_hip_matrix *m, const int *d_row_ptr, const int *d_col, const void *d_val,
                  bool val_is_f64, bool sorted, hipStream_t st)
 {

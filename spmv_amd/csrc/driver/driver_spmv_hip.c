@@ -120,12 +120,14 @@ static spmv_hip_matrix *create_for_mode(const char *mode, int rows, int cols, in
     if (!strcmp(mode, "csr_bal")) return spmv_hip_create_csr_bal(rows, cols, nnz, coo, dtype, 0);
     if (!strcmp(mode, "ell")) return spmv_hip_create_ell(rows, cols, nnz, coo, dtype, 0);
     if (!strcmp(mode, "auto")) return spmv_hip_create_auto(rows, cols, nnz, coo, dtype, 3);   /* format by trial */
-    if (!strcmp(mode, "sellp_vec") || !strcmp(mode, "sellp_autovec") || !strcmp(mode, "sellp_highway") || !strcmp(mode, "sell")) {
+    if (!strcmp(mode, "sellp_vec") || !strcmp(mode, "sellp_autovec") || !strcmp(mode, "sellp_highway") || !strcmp(mode, "sell") ||
+        !strcmp(mode, "sell_dfc")) {
         int *rp, *cj; double *va;
         spmv_hip_sort_coo(nnz, coo);                       /* create_csr's side effect (csr.c:167) */
         coo_to_csr(rows, nnz, coo, &rp, &cj, &va);
-        spmv_hip_matrix *m = !strcmp(mode, "sell") ? spmv_hip_create_sell(rows, cols, nnz, rp, cj, va, dtype, 0, 0)
-                                                   : spmv_hip_create_sellp(rows, cols, nnz, rp, cj, va, dtype, 0);
+        spmv_hip_matrix *m = !strcmp(mode, "sell")       ? spmv_hip_create_sell(rows, cols, nnz, rp, cj, va, dtype, 0, 0)
+                             : !strcmp(mode, "sell_dfc") ? spmv_hip_create_sell_dfc(rows, cols, nnz, rp, cj, va, dtype, 0, 0)
+                                                         : spmv_hip_create_sellp(rows, cols, nnz, rp, cj, va, dtype, 0);
         free(rp); free(cj); free(va);
         return m;
     }
@@ -136,7 +138,7 @@ static spmv_hip_matrix *create_for_mode(const char *mode, int rows, int cols, in
 int main(int argc, char *argv[])
 {
     if (argc != 4) {
-        printf("Usage: spmv_hip [csr_base|csr_vec|csr_merge|csr_bal|sellp_vec|ell|sell][:f32] <mtx list> <output csv>\n");
+        printf("Usage: spmv_hip [csr_base|csr_vec|csr_merge|csr_bal|sellp_vec|ell|sell|sell_dfc|auto][:f32] <mtx list> <output csv>\n");
         exit(-1);
     }
     char mode[64];

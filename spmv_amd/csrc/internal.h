@@ -67,6 +67,11 @@ struct spmv_hip_matrix {
     int *d_row_order = nullptr;     // rows (SELL only)
     int *d_scol = nullptr;          // stored
     void *d_sval = nullptr;         // stored (dtype)
+    // SELL without padding: length of the row at every sorted position, columns per slice, active lanes
+    int *d_sorted_len = nullptr;    // rows
+    int64_t *d_vop_ptr = nullptr;   // nslices+1
+    uint8_t *d_vop_len = nullptr;   // vops
+    int64_t vops = 0;
 
     // staging vectors for the host-pointer multiply and the bench loop
     void *d_x = nullptr, *d_y = nullptr;
@@ -92,6 +97,8 @@ int build_merge_tiles(spmv_hip_matrix *m, hipStream_t stream);
 int build_bal_tiles(spmv_hip_matrix *m, hipStream_t stream);
 int build_sliced(spmv_hip_matrix *m, const int *d_row_ptr, const int *d_col, const void *d_val,
                  bool val_is_f64, bool sorted, hipStream_t stream);
+int build_sell_dfc(spmv_hip_matrix *m, const int *d_row_ptr, const int *d_col, const void *d_val,
+                   bool val_is_f64, hipStream_t stream);
 
 template <typename T> int dev_alloc(spmv_hip_matrix *m, T **p, size_t count)
 {

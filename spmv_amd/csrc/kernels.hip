@@ -405,6 +405,68 @@ __global__ __launch_bounds__(kBlock) void sliced64_wide_kernel(int rows, int nsl
     if (r < rows) y[PERM ? row_order[r] : r] = mine;
 }
 
+// ----------------------------------------- SELL-C-sigma without padding (DFC) --
+// One wave per slice, lane = row (sorted position).  Column v of the slice holds one entry per row
+// longer than v; the rows of a slice are sorted by length, so these are lanes 0..active-1 and the
+// column is one contiguous run starting where the previous column ended.  The run start is carried
+// as a wave-uniform counter (ballot + popcount), so neither vop_len nor vop_ptr is read here.  One
+// fma per entry in ascending column order: the summation order of mult_csr_base (csr.c:4-13).
+template <typename T, int U, bool NT>
+__global__ __launch_bounds__(kBlock) void sell_dfc_kernel(int rows, int nslices,
+                                                          const int64_t *__restrict__ slice_ptr,
+                                                          const int *__restrict__ sorted_len,
+                                                          const int *__restrict__ row_order,
+                                                          const int *__restrict__ scol,
+                                                          const T *__restrict__ sval,
+                                                          const T *__restrict__ x, T *__restrict__ y)
+{
+    unsigned b = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    int s = __builtin_amdgcn_readfirstlane((int)(b * (kBlock / kWave) + threadIdx.x / kWave));
+    if (s >= nslices) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int r = s * kWave + lane;
+    const int len = r < rows ? sorted_len[r] : 0;
+    const int width = __builtin_amdgcn_readfirstlane(len);      // lane 0 holds the slice's longest row
+    const int *c = scol + slice_ptr[s] + lane;
+    const T *v = sval + slice_ptr[s] + lane;
+    const int shortest = __builtin_amdgcn_readlane(len, kWave - 1);   // columns below it hold all 64 lanes
+    int run = 0;                                                // entries of the slice before column j
+    T acc = 0;
+    int j0 = 0;
+    for (; j0 + U <= shortest; j0 += U) {                       // full columns: plain strided slice, no masks
+        int cc[U];
+        T vv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) cc[u] = NT ? __builtin_nontemporal_load(c + run + u * kWave) : c[run + u * kWave];
+#pragma unroll
+        for (int u = 0; u < U; u++) vv[u] = NT ? __builtin_nontemporal_load(v + run + u * kWave) : v[run + u * kWave];
+#pragma unroll
+        for (int u = 0; u < U; u++) acc = fma_t(x[cc[u]], vv[u], acc);
+        run += U * kWave;
+    }
+    for (; j0 < width; j0 += U) {
+        int off[U], cc[U];
+        T vv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            off[u] = run;
+            run += __popcll(__ballot(j0 + u < len));
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            cc[u] = j0 + u < len ? (NT ? __builtin_nontemporal_load(c + off[u]) : c[off[u]]) : 0;
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            vv[u] = j0 + u < len ? (NT ? __builtin_nontemporal_load(v + off[u]) : v[off[u]]) : (T)0;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const T xv = x[cc[u]];
+            if (j0 + u < len) acc = fma_t(xv, vv[u], acc);
+        }
+    }
+    if (r < rows) y[row_order[r]] = acc;
+}
+
 // ------------------------------------- sliced formats, any slice height <= 64 --
 // Lane per row; used for the reference's CPU-shaped slice heights (2, 4, 8).
 
@@ -696,8 +758,11 @@ constexpr int kSlicedVariants[] = {0, 1, 2, 3, 4, 9, 10, 11, 12};
 int variant_candidates(const spmv_hip_matrix *m, int *out, int max_out)
 {
     int n = 0;
-    const bool sliced64 = m->d_slice_ptr && m->slice_height == kWave;
-    if (sliced64) {
+    const bool sliced64 = m->d_slice_ptr && m->slice_height == kWave && m->format != SPMV_HIP_SELL_DFC;
+    if (m->format == SPMV_HIP_SELL_DFC) {
+        for (int v = 0; v <= 4; v++)                          // columns per batch 8, 16, 8 nt, 16 nt, 4
+            if (n < max_out) out[n++] = v;
+    } else if (sliced64) {
         for (int v : kSlicedVariants)
             if (n < max_out) out[n++] = v;
     } else if (m->format == SPMV_HIP_CSR_VECTOR) {
@@ -745,6 +810,27 @@ static int launch_sliced64(const spmv_hip_matrix *m, const T *x, T *y, hipStream
     default: set_error("sliced format: unknown kernel variant %d", m->variant); return 1;
     }
 #undef SPMV_WIDE
+    return 0;
+}
+
+template <typename T> static int launch_sell_dfc(const spmv_hip_matrix *m, const T *x, T *y, hipStream_t st)
+{
+    const dim3 grid(cdiv(m->nslices, kBlock / kWave)), block(kBlock);
+    const T *sv = (const T *)m->d_sval;
+#define SPMV_DFC(V, U, NT)                                                                               \
+    case V:                                                                                              \
+        hipLaunchKernelGGL((sell_dfc_kernel<T, U, NT>), grid, block, 0, st, m->rows, m->nslices, m->d_slice_ptr, \
+                           m->d_sorted_len, m->d_row_order, m->d_scol, sv, x, y);                        \
+        break;
+    switch (m->variant) {
+        SPMV_DFC(0, 8, false)
+        SPMV_DFC(1, 16, false)
+        SPMV_DFC(2, 8, true)
+        SPMV_DFC(3, 16, true)
+        SPMV_DFC(4, 4, false)
+    default: set_error("sell_dfc: unknown kernel variant %d", m->variant); return 1;
+    }
+#undef SPMV_DFC
     return 0;
 }
 
@@ -847,6 +933,7 @@ template <typename T> static int launch_mult_t(const spmv_hip_matrix *m, const T
     case SPMV_HIP_SELL:
     case SPMV_HIP_SELLP:
     case SPMV_HIP_ELL: rc = launch_sliced<T>(m, x, y, st); break;
+    case SPMV_HIP_SELL_DFC: rc = launch_sell_dfc<T>(m, x, y, st); break;
     default: set_error("unknown format %d", m->format); return 1;
     }
     if (rc) return rc;

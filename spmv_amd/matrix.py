@@ -71,6 +71,13 @@ class Matrix:
                                                 sigma))
 
     @classmethod
+    def sell_dfc(cls, rows, columns, row_ptr, col, val, dtype=L.F64, C_=0, sigma=0):
+        """SELL-C-sigma without padding (csr_to_sellcs_dfc, sellcs_format.c:53-136)."""
+        rp, cj, va = _as_csr(row_ptr, col, val)
+        return cls(L.lib().spmv_hip_create_sell_dfc(rows, columns, len(cj), _ptr(rp), _ptr(cj), _ptr(va), dtype, C_,
+                                                    sigma))
+
+    @classmethod
     def auto(cls, rows, columns, coo, dtype=L.F64, reps=3):
         """Fastest of merge / lane-per-row / vector CSR, SELLP, SELL-64-1024 by trial; sorts `coo` in place."""
         coo = _as_coo(coo)
@@ -142,7 +149,12 @@ class Matrix:
     def download(self, which: int) -> np.ndarray:
         info = self.info
         vt = _NP[info.dtype]
+        if which == L.ARR_VOP_LEN:                      # one byte per column; the count is the last vop pointer
+            out = np.empty(int(self.download(L.ARR_VOP_PTR)[-1]), np.uint8)
+            L.check(L.lib().spmv_hip_download(self._h, which, _ptr(out), out.nbytes))
+            return out
         shape, dt = {
+            L.ARR_VOP_PTR: (info.nslices + 1, np.int64),
             L.ARR_ROW_PTR: (info.rows + 1, np.int32),
             L.ARR_COL: (info.stored, np.int32),
             L.ARR_VAL: (info.stored, vt),
@@ -239,12 +251,14 @@ def create(mode: str, rows: int, columns: int, coo: np.ndarray, dtype=L.F64, sig
         return Matrix.csr_bal(rows, columns, coo, dtype)
     if mode == "ell":                                        # :236-238
         return Matrix.ell(rows, columns, coo, dtype)
-    if mode in ("sellp_vec", "sellp_autovec", "sellp_highway", "sell"):
+    if mode in ("sellp_vec", "sellp_autovec", "sellp_highway", "sell", "sell_dfc"):
         # :206-221,239-247: create_csr(alignment 1) first, then the sliced format from its arrays
         sort_coo(coo)                                        # create_csr's side effect (csr.c:167)
         rp, cj, va = coo_to_csr_host(rows, coo)
         if mode == "sell":
             return Matrix.sell(rows, columns, rp, cj, va, dtype, 0, sigma)
+        if mode == "sell_dfc":                               # no reference MODE: its DFC layout has no CPU kernel
+            return Matrix.sell_dfc(rows, columns, rp, cj, va, dtype, 0, sigma)
         return Matrix.sellp(rows, columns, rp, cj, va, dtype)
     if mode == "auto":                                       # no reference MODE: format chosen by trial
         return Matrix.auto(rows, columns, coo, dtype)

@@ -40,6 +40,7 @@ FORMATS = {
     "ell": (S.ELL, 0, 0),
     "sellp_vec": (S.SELLP, 0, 0),
     "sell": (S.SELL, 64, 1024),
+    "sell_dfc": (S.SELL_DFC, 64, 1024),
     "auto": (-1, 0, 0),
 }
 TOLERANCE = {S.F64: 1e-10, S.F32: 1e-5}

@@ -56,12 +56,13 @@ def test_every_format_on_random_shapes(orc, seed):
         "csr_bal": lambda dt: Matrix.csr_bal(rows, cols, coo.copy(), dt),
         "sell_64": lambda dt: Matrix.sell(rows, cols, rp, cj, va, dt, 64, 64),
         "sell_1024": lambda dt: Matrix.sell(rows, cols, rp, cj, va, dt, 64, 1024),
+        "sell_dfc": lambda dt: Matrix.sell_dfc(rows, cols, rp, cj, va, dt, 64, 1024),
         "sellp": lambda dt: Matrix.sellp(rows, cols, rp, cj, va, dt),
         "sellp_8": lambda dt: Matrix.sellp(rows, cols, rp, cj, va, dt, 8),
         "ell": lambda dt: Matrix.ell(rows, cols, coo.copy(), dt),
         "auto": lambda dt: Matrix.auto(rows, cols, coo.copy(), dt, 1),
     }
-    exact = {"csr_scalar", "sell_64", "sell_1024", "sellp", "sellp_8", "ell"}
+    exact = {"csr_scalar", "sell_64", "sell_1024", "sell_dfc", "sellp", "sellp_8", "ell"}
     for name, build in builders.items():
         m = build(S.F64)
         assert m.info.nnz == nnz

@@ -167,6 +167,34 @@ def test_sell_layout_and_product(g, sigma):
         assert bits_equal(y, g[f"y_sell_s{sigma}"])
 
 
+@pytest.mark.parametrize("sigma", [64, 1024])
+def test_sell_dfc_layout_and_product(orc, g, sigma):
+    """SELL-C-sigma without padding: the layout of the reference's csr_to_sellcs_dfc (oracle restatement,
+    itself checked against the compiled reference) bit for bit; product in mult_csr_base's order."""
+    rows, cols = int(g["rows"]), int(g["cols"])
+    csr = (g["csr1_row_ptr"], g["csr1_col"], g["csr1_val"])
+    want = orc.sell_dfc_from_csr(*csr, 64, sigma)
+    m = Matrix.sell_dfc(rows, cols, *csr, S.F64, 64, sigma)
+    info = m.info
+    assert info.format == S.SELL_DFC and info.stored == info.nnz == len(csr[1]) and info.slice_height == 64
+    assert bits_equal(m.download(S.ARR_ROW_ORDER), want["row_order"])
+    assert bits_equal(m.download(S.ARR_VOP_PTR), want["vop_ptr"])
+    assert bits_equal(m.download(S.ARR_VOP_LEN), want["vop_len"])
+    assert bits_equal(m.download(S.ARR_SLICE_PTR), want["slice_ptr"])
+    assert bits_equal(m.download(S.ARR_COL), want["col"])
+    assert bits_equal(m.download(S.ARR_VAL), want["val"])
+    for v in range(5):
+        m.set_option("variant", v)
+        assert bits_equal(m.mult(g["x"]), g["y_csr_base"]), v
+    assert m.analyze(2) in range(5)
+    m.free()
+    x32 = g["x"].astype(np.float32)
+    m = Matrix.sell_dfc(rows, cols, *csr, S.F32, 64, sigma)
+    y32 = orc.mult_csr_base_f32(csr[0], csr[1], csr[2].astype(np.float32), x32)
+    assert bits_equal(m.mult(x32.astype(np.float64)).astype(np.float32), y32)
+    m.free()
+
+
 def test_sell_window_with_a_very_long_row(orc):
     """A row of 2^17 entries or more takes the counting path of the window sort: same order as the reference's."""
     n = (1 << 17) + 640
@@ -423,7 +451,7 @@ def test_create_free_cycles_return_all_device_memory():
     x = np.ones(cols)
 
     def cycle():
-        for mode in list(S.MODES) + ["auto"]:
+        for mode in list(S.MODES) + ["auto", "sell_dfc"]:
             m = S.create(mode, rows, cols, coo.copy())
             m.analyze(1)
             m.mult(x)

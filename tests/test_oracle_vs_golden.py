@@ -105,6 +105,28 @@ def test_sell_layout_and_product(orc, g, sigma):
     assert bits_equal(y, g["y_csr_base"])
 
 
+@pytest.mark.parametrize("sigma", CS.SELL_SIGMAS)
+def test_sell_dfc_is_the_sell_layout_without_its_padding(orc, g, sigma):
+    """csr_to_sellcs_dfc (sellcs_format.c:53-136) against the padded layout of the fixtures: same row order
+    and widths; dropping the padding of every column of every slice gives exactly the DFC arrays."""
+    D = orc.sell_dfc_from_csr(g["csr1_row_ptr"], g["csr1_col"], g["csr1_val"], 64, sigma)
+    assert bits_equal(D["row_order"], g[f"sell_s{sigma}_row_order"])
+    assert bits_equal(D["slice_widths"], g[f"sell_s{sigma}_slice_widths"])
+    sp, sc, sv = g[f"sell_s{sigma}_slice_ptr"], g[f"sell_s{sigma}_col"], g[f"sell_s{sigma}_val"]
+    lens = D["rows_size_sorted"]
+    cols, vals, active = [], [], []
+    for s, w in enumerate(D["slice_widths"]):
+        ls = lens[s * 64:(s + 1) * 64]
+        for v in range(int(w)):
+            a = int((ls > v).sum())
+            active.append(a - 1)
+            cols.append(sc[sp[s] + 64 * v: sp[s] + 64 * v + a]); vals.append(sv[sp[s] + 64 * v: sp[s] + 64 * v + a])
+    assert bits_equal(D["vop_len"], np.array(active, np.uint8))
+    assert bits_equal(D["col"], np.concatenate(cols) if cols else np.zeros(0, np.int32))
+    assert bits_equal(D["val"], np.concatenate(vals) if vals else np.zeros(0))
+    assert bits_equal(orc.mult_sell_dfc(D, g["x"]), g["y_csr_base"])
+
+
 def test_sellp_and_ell_layout_and_product(orc, g):
     E = orc.sliced_ell_from_csr(g["csr1_row_ptr"], g["csr1_col"], g["csr1_val"], 4)
     assert bits_equal(E["block_ptr"], g["sellp4_block_ptr"])

@@ -67,6 +67,17 @@ def test_oracle_equals_compiled_reference(seed):
         assert oracle.as_np(R.ref_sell_column_indices(s), int(sp[-1]), np.int32).tobytes() == S["col"].tobytes()
         assert oracle.as_np(R.ref_sell_values(s), int(sp[-1]), np.float64).tobytes() == S["val"].tobytes()
         assert oracle.mult_sell(S, np.ascontiguousarray(x)).tobytes() == y_base.tobytes()
+        # the same conversion with enable_dfc = 1 (sellcs_format.c:53-136): no padding, active lanes per column
+        d = R.ref_create_sell_dfc(c, 64, sigma)
+        D = oracle.sell_dfc_from_csr(rp, cj, va, 64, sigma)
+        vops = int(D["vop_ptr"][-1])
+        assert oracle.as_np(R.ref_sell_row_order(d), rows, np.int32).tobytes() == D["row_order"].tobytes()
+        assert oracle.as_np(R.ref_sell_vop_pointers(d), ns + 1, np.uint64).astype(np.int64).tobytes() == D["vop_ptr"].tobytes()
+        assert oracle.as_np(R.ref_sell_vop_lengths(d), vops, np.uint8).tobytes() == D["vop_len"].tobytes()
+        assert oracle.as_np(R.ref_sell_slice_pointers(d), ns + 1, np.int32).astype(np.int64).tobytes() == D["slice_ptr"].tobytes()
+        assert oracle.as_np(R.ref_sell_column_indices(d), nnz, np.int32).tobytes() == D["col"].tobytes()
+        assert oracle.as_np(R.ref_sell_values(d), nnz, np.float64).tobytes() == D["val"].tobytes()
+        assert oracle.mult_sell_dfc(D, np.ascontiguousarray(x)).tobytes() == y_base.tobytes()
 
     sp_ = R.ref_create_sellp(rows, cols, nnz, rp, cj, va)
     E = oracle.sliced_ell_from_csr(rp, cj, va, R.ref_block())

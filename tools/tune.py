@@ -44,7 +44,7 @@ def main():
     nnz = int(rp[-1])
     b_alg = nnz * (vb + 4) + rows * (4 + vb) + cols * vb
     fmt = {"sell": S.SELL, "sellp": S.SELLP, "ell": S.ELL, "csr_scalar": S.CSR_SCALAR, "csr_vector": S.CSR_VECTOR,
-           "csr_merge": S.CSR_MERGE, "csr_bal": S.CSR_BAL}[args.format]
+           "csr_merge": S.CSR_MERGE, "csr_bal": S.CSR_BAL, "sell_dfc": S.SELL_DFC}[args.format]
     st = torch.cuda.current_stream().cuda_stream
     g = torch.Generator(device=dev).manual_seed(1)
     x = torch.rand(cols, dtype=td, device=dev, generator=g)
@@ -52,9 +52,9 @@ def main():
     y0 = None
     print(f"# {args.format} {args.matrix} n={args.n} {args.dtype}: rows {rows} nnz {nnz} B_alg {b_alg / 1e9:.3f} GB")
     for p0 in [int(v) for v in args.p0.split(",")]:
-        pp0 = p0 or (64 if fmt == S.SELL else 0)
+        pp0 = p0 or (64 if fmt in (S.SELL, S.SELL_DFC) else 0)
         m = Matrix.from_device_csr(fmt, rows, cols, nnz, rp.data_ptr(), cj.data_ptr(), va.data_ptr(), dtype, pp0,
-                                   args.sigma if fmt == S.SELL else 0, st)
+                                   args.sigma if fmt in (S.SELL, S.SELL_DFC) else 0, st)
         for var in [v if v == "auto" else int(v) for v in args.variants.split(",")]:
             if var == "auto":
                 m.analyze(3)
