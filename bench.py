@@ -3,7 +3,7 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-N = 1: BASELINE.json configs[1] -- SELL-C-sigma (C=64, sigma=1024) fp64 on the
+N = 1: the headline configuration -- SELL-C-sigma (C=64, sigma=1024) fp64 on the
 synthetic 3-D 27-point stencil 252^3 (16 003 008 rows, 428 661 064 nnz), matrix
 and vectors resident in HBM before the timed region.  A step is one y = A*x.
 N > 1 (weak scaling): every rank owns a z-slab of 252 planes of a 252 x 252 x
@@ -158,7 +158,7 @@ def main():
             workload = f"stencil27 {n}^3"
         else:
             plane = n * n
-            nzp = args.planes or n          # BASELINE configs[3] (530^3 over 8 GPUs): --size 530 --planes 66
+            nzp = args.planes or n          # 530^3 over 8 GPUs: --size 530 --planes 66
             r0, r1 = rank * nzp * plane, (rank + 1) * nzp * plane
             rows, cols, rp, cj, va = G.stencil27(n, n, nzp * world, device=dev, row_begin=r0, row_end=r1)
             workload = f"stencil27 {n}x{n}x{nzp * world}, z-slab of {nzp} planes per GPU"
