@@ -306,6 +306,7 @@ template <typename T, bool PERM, int U>
 __global__ __launch_bounds__(kBlock) void sliced64_kernel(int rows, int nslices,
                                                           const int64_t *__restrict__ slice_ptr,
                                                           const int *__restrict__ row_order,
+                                                          const unsigned char *__restrict__ slice_ident,
                                                           const int *__restrict__ scol,
                                                           const T *__restrict__ sval,
                                                           const T *__restrict__ x, T *__restrict__ y)
@@ -334,7 +335,8 @@ __global__ __launch_bounds__(kBlock) void sliced64_kernel(int rows, int nslices,
     }
     for (; j < width; j++) acc = fma_t(x[c[(int64_t)j * kWave]], v[(int64_t)j * kWave], acc);
     int r = s * kWave + lane;
-    if (r < rows) y[PERM ? row_order[r] : r] = acc;
+    // slices whose rows kept their places (flagged at build time) skip the row_order lookup
+    if (r < rows) y[PERM && !slice_ident[s] ? row_order[r] : r] = acc;
 }
 
 // sliced64_wide_kernel: the same slices read with 16-byte loads.  Lane l =
@@ -351,6 +353,7 @@ template <typename T, bool PERM, int U, bool NT>
 __global__ __launch_bounds__(kBlock) void sliced64_wide_kernel(int rows, int nslices,
                                                                const int64_t *__restrict__ slice_ptr,
                                                                const int *__restrict__ row_order,
+                                                               const unsigned char *__restrict__ slice_ident,
                                                                const int *__restrict__ scol,
                                                                const T *__restrict__ sval,
                                                                const T *__restrict__ x, T *__restrict__ y)
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(kBlock) void sliced64_wide_kernel(int rows, int nsl
         if ((lane % R) == k) mine = from;
     }
     int r = s * kWave + lane;
-    if (r < rows) y[PERM ? row_order[r] : r] = mine;
+    if (r < rows) y[PERM && !slice_ident[s] ? row_order[r] : r] = mine;
 }
 
 // ----------------------------------------- SELL-C-sigma without padding (DFC) --
@@ -793,11 +796,11 @@ static int launch_sliced64(const spmv_hip_matrix *m, const T *x, T *y, hipStream
     const T *sv = (const T *)m->d_sval;
 #define SPMV_WIDE(U, NT)                                                                                   \
     hipLaunchKernelGGL((sliced64_wide_kernel<T, PERM, U, NT>), grid, block, 0, st, m->rows, m->nslices,    \
-                       m->d_slice_ptr, m->d_row_order, m->d_scol, sv, x, y)
+                       m->d_slice_ptr, m->d_row_order, m->d_slice_ident, m->d_scol, sv, x, y)
     switch (m->variant) {
     case 0:
         hipLaunchKernelGGL((sliced64_kernel<T, PERM, 8>), grid, block, 0, st, m->rows, m->nslices, m->d_slice_ptr,
-                           m->d_row_order, m->d_scol, sv, x, y);
+                           m->d_row_order, m->d_slice_ident, m->d_scol, sv, x, y);
         break;
     case 1: SPMV_WIDE(2, false); break;
     case 2: SPMV_WIDE(4, false); break;
