@@ -470,6 +470,91 @@ __global__ __launch_bounds__(kBlock) void sell_dfc_kernel(int rows, int nslices,
     if (r < rows) y[row_order[r]] = acc;
 }
 
+// The same product with the partial columns staged through LDS.  The columns below the slice's
+// shortest row are read as above.  The rest of the slice is one contiguous run of entries: it is
+// loaded in line-aligned chunks of 64*IPL entries by all 64 lanes, gathered, parked in LDS as (x, value)
+// pairs, and then walked column by column -- lane k takes entry k of the column while the column has
+// one.  Every HBM access is a full-width one whatever the number of active lanes, so slices with a
+// long thin tail cost their entries, not their width.  Same summation order.
+template <typename T, int IPL, bool NT>
+__global__ __launch_bounds__(kWave) void sell_dfc_lds_kernel(int rows, int nslices,
+                                                             const int64_t *__restrict__ slice_ptr,
+                                                             const int *__restrict__ sorted_len,
+                                                             const int *__restrict__ row_order,
+                                                             const int *__restrict__ scol,
+                                                             const T *__restrict__ sval,
+                                                             const T *__restrict__ x, T *__restrict__ y)
+{
+    constexpr int kCap = kWave * IPL, U = 8;
+    __shared__ xv_pair<T> stage[kCap];
+    const int s = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int lane = threadIdx.x;
+    const int r = s * kWave + lane;
+    const int len = r < rows ? sorted_len[r] : 0;
+    const int width = __builtin_amdgcn_readfirstlane(len);
+    const int shortest = __builtin_amdgcn_readlane(len, kWave - 1);
+    const int64_t base = slice_ptr[s], slice_end = slice_ptr[s + 1];
+    const int *c = scol + base + lane;
+    const T *v = sval + base + lane;
+    int64_t run = 0;
+    T acc = 0;
+    int j = 0;
+    for (; j + U <= shortest; j += U) {
+        int cc[U];
+        T vv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) cc[u] = NT ? __builtin_nontemporal_load(c + run + u * kWave) : c[run + u * kWave];
+#pragma unroll
+        for (int u = 0; u < U; u++) vv[u] = NT ? __builtin_nontemporal_load(v + run + u * kWave) : v[run + u * kWave];
+#pragma unroll
+        for (int u = 0; u < U; u++) acc = fma_t(x[cc[u]], vv[u], acc);
+        run += U * kWave;
+    }
+    while (j < width) {
+        const int64_t g0 = base + run;                         // first entry of column j in the arrays
+        const int64_t ga = g0 & ~(int64_t)31;                  // chunk start on a 128-byte line of scol
+        int cc[IPL];
+        T vv[IPL];
+#pragma unroll
+        for (int i = 0; i < IPL; i++) {
+            const int64_t at = min(max(ga + lane + i * kWave, g0), slice_end - 1);
+            cc[i] = NT ? __builtin_nontemporal_load(scol + at) : scol[at];
+            vv[i] = NT ? __builtin_nontemporal_load(sval + at) : sval[at];
+        }
+#pragma unroll
+        for (int i = 0; i < IPL; i++) stage[lane + i * kWave] = xv_pair<T>{x[cc[i]], vv[i]};
+        __syncthreads();
+        int pos = (int)(g0 - ga);                              // LDS position of column j
+        while (j < width) {
+            if (j + 4 <= width) {                              // four columns at a time while they fit
+                int p[4], q = pos;
+#pragma unroll
+                for (int u = 0; u < 4; u++) { p[u] = q; q += __popcll(__ballot(j + u < len)); }
+                if (q <= kCap) {
+                    xv_pair<T> e[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) e[u] = stage[min(p[u] + lane, kCap - 1)];
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (j + u < len) acc = fma_t(e[u].x, e[u].v, acc);
+                    run += q - pos;
+                    pos = q;
+                    j += 4;
+                    continue;
+                }
+            }
+            const int a = __popcll(__ballot(j < len));
+            if (pos + a > kCap) break;                         // column j straddles the chunk: reload from it
+            if (j < len) { const xv_pair<T> e = stage[pos + lane]; acc = fma_t(e.x, e.v, acc); }
+            pos += a;
+            run += a;
+            j++;
+        }
+        __syncthreads();
+    }
+    if (r < rows) y[row_order[r]] = acc;
+}
+
 // ------------------------------------- sliced formats, any slice height <= 64 --
 // Lane per row; used for the reference's CPU-shaped slice heights (2, 4, 8).
 
@@ -763,7 +848,7 @@ int variant_candidates(const spmv_hip_matrix *m, int *out, int max_out)
     int n = 0;
     const bool sliced64 = m->d_slice_ptr && m->slice_height == kWave && m->format != SPMV_HIP_SELL_DFC;
     if (m->format == SPMV_HIP_SELL_DFC) {
-        for (int v = 0; v <= 4; v++)                          // columns per batch 8, 16, 8 nt, 16 nt, 4
+        for (int v = 0; v <= 8; v++)                          // see launch_sell_dfc
             if (n < max_out) out[n++] = v;
     } else if (sliced64) {
         for (int v : kSlicedVariants)
@@ -825,14 +910,26 @@ template <typename T> static int launch_sell_dfc(const spmv_hip_matrix *m, const
         hipLaunchKernelGGL((sell_dfc_kernel<T, U, NT>), grid, block, 0, st, m->rows, m->nslices, m->d_slice_ptr, \
                            m->d_sorted_len, m->d_row_order, m->d_scol, sv, x, y);                        \
         break;
+#define SPMV_DFC_LDS(V, I, NT)                                                                           \
+    case V:                                                                                              \
+        hipLaunchKernelGGL((sell_dfc_lds_kernel<T, I, NT>), dim3((unsigned)m->nslices), dim3(kWave), 0, st, m->rows, \
+                           m->nslices, m->d_slice_ptr, m->d_sorted_len, m->d_row_order, m->d_scol, sv, x, y); \
+        break;
+    // 0..4: partial columns as masked loads (8, 16, 8 nt, 16 nt, 4 columns per batch);
+    // 5..8: partial columns staged through LDS (chunks of 512, 512 nt, 256, 1024 entries)
     switch (m->variant) {
         SPMV_DFC(0, 8, false)
         SPMV_DFC(1, 16, false)
         SPMV_DFC(2, 8, true)
         SPMV_DFC(3, 16, true)
         SPMV_DFC(4, 4, false)
+        SPMV_DFC_LDS(5, 8, false)
+        SPMV_DFC_LDS(6, 8, true)
+        SPMV_DFC_LDS(7, 4, false)
+        SPMV_DFC_LDS(8, 16, false)
     default: set_error("sell_dfc: unknown kernel variant %d", m->variant); return 1;
     }
+#undef SPMV_DFC_LDS
 #undef SPMV_DFC
     return 0;
 }

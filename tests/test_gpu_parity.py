@@ -183,10 +183,10 @@ def test_sell_dfc_layout_and_product(orc, g, sigma):
     assert bits_equal(m.download(S.ARR_SLICE_PTR), want["slice_ptr"])
     assert bits_equal(m.download(S.ARR_COL), want["col"])
     assert bits_equal(m.download(S.ARR_VAL), want["val"])
-    for v in range(5):
+    for v in range(9):                              # masked-load and LDS-staged handling of the partial columns
         m.set_option("variant", v)
         assert bits_equal(m.mult(g["x"]), g["y_csr_base"]), v
-    assert m.analyze(2) in range(5)
+    assert m.analyze(2) in range(9)
     m.free()
     x32 = g["x"].astype(np.float32)
     m = Matrix.sell_dfc(rows, cols, *csr, S.F32, 64, sigma)
