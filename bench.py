@@ -44,6 +44,8 @@ def parse_args():
     ap.add_argument("--sigma", type=int, default=1024)
     ap.add_argument("--p0", type=int, default=0, help="format parameter (lanes per row / tile size / slice height)")
     ap.add_argument("--exchange", default="halo", choices=["halo", "allgather"])
+    ap.add_argument("--comm-breakdown", action="store_true",
+                    help="N > 1: after the timed region also time the exchange alone and the local products alone")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=100, help="stencil edge of the CPU-baseline sample")
     return ap.parse_args()
@@ -240,7 +242,7 @@ def main():
     # outside the timed region: the exchange alone and the local products alone, to say how much of
     # the communication the overlap hides (max over ranks of per-step means)
     comm = None
-    if world > 1:
+    if world > 1 and args.comm_breakdown:
         def timed_ms(fn, reps=10):
             fn()
             torch.cuda.synchronize()
