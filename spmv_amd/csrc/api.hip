@@ -199,6 +199,31 @@ static spmv_hip_matrix *create_from_coo(int format, int rows, int columns, int n
     clear_error();
     if (check_dims(rows, columns, nnz, dtype)) return nullptr;
     if (nnz > 0 && !coo) { set_error("coo is NULL"); return nullptr; }
+    // large unpadded inputs: sort and COO -> CSR in HBM (one upload of the COO instead of a host pass
+    // over it and an upload of the CSR); SPMV_HIP_DEVICE_CSR_MIN moves the threshold
+    const char *env = getenv("SPMV_HIP_DEVICE_CSR_MIN");
+    const long device_min = env ? atol(env) : (1L << 22);
+    if (alignment == 1 && nnz >= device_min) {
+        const bool sliced = format == SPMV_HIP_SELL || format == SPMV_HIP_SELLP || format == SPMV_HIP_ELL ||
+                            format == SPMV_HIP_SELL_DFC;
+        const bool values_f64 = sliced || dtype == SPMV_HIP_F64;
+        int *d_rp = nullptr, *d_cj = nullptr;
+        void *d_va = nullptr;
+        const int rc = device_coo_to_csr(rows, columns, nnz, coo, values_f64, &d_rp, &d_cj, &d_va);
+        if (rc == 1) return nullptr;
+        if (rc == 0) {
+            clear_error();
+            spmv_hip_matrix *m = new_handle(format, dtype, rows, columns, nnz);
+            if (!m) { (void)hipFree(d_rp); (void)hipFree(d_cj); (void)hipFree(d_va); return nullptr; }
+            m->owns_csr = true;
+            m->stored = nnz;
+            m->d_row_ptr = d_rp; m->d_col = d_cj; m->d_val = d_va;
+            m->device_bytes = (int64_t)sizeof(int) * ((int64_t)rows + 1) + (int64_t)nnz * (int64_t)(sizeof(int) + (values_f64 ? 8 : 4));
+            if (finish_from_device_csr(m, p0, p1, values_f64, nullptr)) { spmv_hip_free(m); return nullptr; }
+            return m;
+        }
+        clear_error();                                        // the device path could not run: host conversion
+    }
     sort_coo_in_place(nnz, coo);
     std::vector<int> rp, cj;
     std::vector<double> va;

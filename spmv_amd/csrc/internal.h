@@ -94,6 +94,8 @@ int launch_scale(int n, const void *d_y, void *d_x, int dtype, const double *d_n
 // creator hands over dtype elements).
 int choose_lanes_per_row(int rows, int64_t stored);
 int device_exclusive_scan(const int *d_in, int *d_out, size_t n, hipStream_t stream);   // sort.hip (rocPRIM)
+int device_coo_to_csr(int rows, int columns, int64_t nnz, struct mtx *coo, bool values_f64, int **d_row_ptr,
+                      int **d_col, void **d_val);                                         // sort.hip
 int build_merge_tiles(spmv_hip_matrix *m, hipStream_t stream);
 int build_bal_tiles(spmv_hip_matrix *m, hipStream_t stream);
 int build_sliced(spmv_hip_matrix *m, const int *d_row_ptr, const int *d_col, const void *d_val,

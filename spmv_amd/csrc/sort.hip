@@ -83,6 +83,105 @@ int device_sort_coo(int64_t nnz, struct mtx *coo)
     return rc;
 }
 
+// ---- COO -> CSR in HBM (create_csr, reference csr.c:160-203, alignment 1) ----
+
+// flags[0]: some entry precedes its predecessor in (row, col) order; [1]: a row index outside [0, rows);
+// [2]: a column index outside [0, columns)
+__global__ void coo_check_kernel(int64_t n, int rows, int columns, const struct mtx *__restrict__ coo,
+                                 int *__restrict__ flags)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const struct mtx e = coo[k];
+    if (e.i < 0 || e.i >= rows) flags[1] = 1;
+    if (e.j < 0 || e.j >= columns) flags[2] = 1;
+    if (k > 0) {
+        const struct mtx p = coo[k - 1];
+        if (p.i > e.i || (p.i == e.i && p.j > e.j)) flags[0] = 1;
+    }
+}
+
+// row_ptr[r] = number of entries with row index < r (entries sorted by row)
+__global__ void coo_row_ptr_kernel(int rows, int64_t n, const struct mtx *__restrict__ coo, int *__restrict__ row_ptr)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > rows) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (coo[mid].i < r) lo = mid + 1; else hi = mid;
+    }
+    row_ptr[r] = (int)lo;
+}
+
+template <typename T>
+__global__ void coo_split_kernel(int64_t n, const struct mtx *__restrict__ coo, int *__restrict__ col, T *__restrict__ val)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    col[k] = coo[k].j;
+    val[k] = (T)coo[k].a;
+}
+
+// Sorts `coo` (host array, in place, as every creator does) and builds its CSR arrays in HBM.
+// Returns 0 with three hipMalloc'ed arrays, 1 on an input error (message set), 2 when the device
+// path could not run (nothing changed; the caller falls back to the host conversion).
+int device_coo_to_csr(int rows, int columns, int64_t nnz, struct mtx *coo, bool values_f64, int **out_rp, int **out_cj,
+                      void **out_va)
+{
+    const size_t n = (size_t)nnz;
+    struct mtx *d_coo = nullptr;
+    uint64_t *d_key[2] = {nullptr, nullptr};
+    double *d_val[2] = {nullptr, nullptr};
+    void *d_temp = nullptr;
+    int *d_flags = nullptr, *d_rp = nullptr, *d_cj = nullptr;
+    void *d_va = nullptr;
+    int rc = 2;
+    do {
+        if (hipMalloc((void **)&d_coo, n * sizeof(struct mtx)) != hipSuccess || hipMalloc((void **)&d_flags, 3 * sizeof(int)) != hipSuccess) break;
+        if (hipMemcpy(d_coo, coo, n * sizeof(struct mtx), hipMemcpyHostToDevice) != hipSuccess) break;
+        if (hipMemset(d_flags, 0, 3 * sizeof(int)) != hipSuccess) break;
+        const dim3 grid((unsigned)((nnz + 255) / 256)), block(256);
+        hipLaunchKernelGGL(coo_check_kernel, grid, block, 0, nullptr, nnz, rows, columns, d_coo, d_flags);
+        int flags[3] = {0, 0, 0};
+        if (hipMemcpy(flags, d_flags, sizeof flags, hipMemcpyDeviceToHost) != hipSuccess) break;
+        if (flags[1]) { set_error("coo row index out of range [0, %d)", rows); rc = 1; break; }
+        if (flags[2]) { set_error("column index out of range [0, %d)", columns); rc = 1; break; }
+        if (flags[0]) {                                       // not in (row, col) order: radix sort, hand the order back
+            bool ok = true;
+            for (int b = 0; b < 2 && ok; b++)
+                ok = hipMalloc((void **)&d_key[b], n * sizeof(uint64_t)) == hipSuccess &&
+                     hipMalloc((void **)&d_val[b], n * sizeof(double)) == hipSuccess;
+            if (!ok) break;
+            hipLaunchKernelGGL(coo_pack_kernel, grid, block, 0, nullptr, nnz, d_coo, d_key[0], d_val[0]);
+            size_t temp_bytes = 0;
+            if (rocprim::radix_sort_pairs(nullptr, temp_bytes, d_key[0], d_key[1], d_val[0], d_val[1], n, 0, 64,
+                                          (hipStream_t) nullptr) != hipSuccess) break;
+            if (hipMalloc(&d_temp, std::max<size_t>(temp_bytes, 16)) != hipSuccess) break;
+            if (rocprim::radix_sort_pairs(d_temp, temp_bytes, d_key[0], d_key[1], d_val[0], d_val[1], n, 0, 64,
+                                          (hipStream_t) nullptr) != hipSuccess) break;
+            hipLaunchKernelGGL(coo_unpack_kernel, grid, block, 0, nullptr, nnz, d_key[1], d_val[1], d_coo);
+            if (hipMemcpy(coo, d_coo, n * sizeof(struct mtx), hipMemcpyDeviceToHost) != hipSuccess) break;
+        }
+        const size_t vbytes = values_f64 ? sizeof(double) : sizeof(float);
+        if (hipMalloc((void **)&d_rp, ((size_t)rows + 1) * sizeof(int)) != hipSuccess ||
+            hipMalloc((void **)&d_cj, n * sizeof(int)) != hipSuccess || hipMalloc(&d_va, n * vbytes) != hipSuccess) break;
+        hipLaunchKernelGGL(coo_row_ptr_kernel, dim3((unsigned)((rows + 256) / 256)), block, 0, nullptr, rows, nnz, d_coo, d_rp);
+        if (values_f64)
+            hipLaunchKernelGGL((coo_split_kernel<double>), grid, block, 0, nullptr, nnz, d_coo, d_cj, (double *)d_va);
+        else
+            hipLaunchKernelGGL((coo_split_kernel<float>), grid, block, 0, nullptr, nnz, d_coo, d_cj, (float *)d_va);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) break;
+        *out_rp = d_rp; *out_cj = d_cj; *out_va = d_va;
+        d_rp = nullptr; d_cj = nullptr; d_va = nullptr;
+        rc = 0;
+    } while (0);
+    void *scratch[] = {d_coo, d_key[0], d_key[1], d_val[0], d_val[1], d_temp, d_flags, d_rp, d_cj, d_va};
+    for (void *p : scratch)
+        if (p) (void)hipFree(p);
+    return rc;
+}
+
 // out[i] = in[0] + ... + in[i-1] on `st` (rocPRIM device scan; its temporary storage is freed before return)
 int device_exclusive_scan(const int *d_in, int *d_out, size_t n, hipStream_t st)
 {

@@ -418,6 +418,39 @@ def test_bench_loop_is_the_drivers_power_iteration(orc, g):
     assert rel(orc, x_last, x) <= 1e-12
 
 
+def test_coo_to_csr_in_hbm_equals_the_host_conversion(g, monkeypatch):
+    """create_csr (csr.c:160-203) done in HBM for large inputs: same arrays, same in-place sort of the
+    caller's COO, same products as the host conversion."""
+    rows, cols = int(g["rows"]), int(g["cols"])
+    monkeypatch.setenv("SPMV_HIP_DEVICE_CSR_MIN", "1")
+    coo = coo_of(g, "in")
+    m = Matrix.csr(rows, cols, coo, 1, S.F64, S.CSR_SCALAR)
+    assert bits_equal(coo["i"], g["coo_sorted_i"]) and bits_equal(coo["j"], g["coo_sorted_j"])
+    assert bits_equal(coo["a"], g["coo_sorted_a"])
+    assert bits_equal(m.download(S.ARR_ROW_PTR), g["csr1_row_ptr"])
+    assert bits_equal(m.download(S.ARR_COL), g["csr1_col"])
+    assert bits_equal(m.download(S.ARR_VAL), g["csr1_val"])
+    assert bits_equal(m.mult(g["x"]), g["y_csr_base"])
+    m.free()
+    m = Matrix.csr(rows, cols, coo_of(g, "in"), 1, S.F32, S.CSR_SCALAR)
+    assert bits_equal(m.download(S.ARR_VAL), g["csr1_val"].astype(np.float32))
+    m.free()
+    for mode in ("csr_merge", "csr_bal", "ell", "auto"):
+        m = S.create(mode, rows, cols, coo_of(g, "in"))
+        assert orc_rel(m.mult(g["x"]), g["y_csr_base"]) <= TOL_REASSOC, mode
+        m.free()
+    if len(g["csr1_col"]):
+        bad = coo_of(g, "in")
+        bad["j"][0] = cols
+        with pytest.raises(S.SpmvHipError, match="column index"):
+            Matrix.csr(rows, cols, bad, 1, S.F64, S.CSR_SCALAR)
+
+
+def orc_rel(y, ref):
+    import oracle
+    return oracle.rel_l2(np.asarray(y, np.float64), np.asarray(ref, np.float64))
+
+
 def test_large_coo_is_sorted_in_hbm_like_the_host_sort(orc, monkeypatch):
     """sort_mtx order (mtx.c:9-34) from the device radix sort: same array as the host sort, stable for duplicates."""
     from spmv_amd.matrix import sort_coo

@@ -56,6 +56,14 @@ def main():
     b[:] = big
     timed("sort_coo in HBM (incl. both PCIe copies), again", lambda: sort_coo(b))
     assert a.tobytes() == b.tobytes()
+    # the whole creator from an unsorted host COO: sort + COO -> CSR + upload
+    dim = 1 << 22
+    for label, csr_min, sort_min in (("on the host", 10 ** 12, 10 ** 12), ("in HBM", 1, 1)):
+        os.environ["SPMV_HIP_DEVICE_CSR_MIN"] = str(csr_min)
+        os.environ["SPMV_HIP_DEVICE_SORT_MIN"] = str(sort_min)
+        c = big.copy()
+        m = timed(f"create_csr from the unsorted COO, {label}", lambda: S.Matrix.csr(dim, dim, c, 1, S.F64, S.CSR_SCALAR))
+        m.free()
 
 
 if __name__ == "__main__":
