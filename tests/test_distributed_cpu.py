@@ -60,6 +60,13 @@ def _worker(rank, world, port, exchange, kind, out_q):
             per = (nz // world) * nx * ny
             r0, r1 = rank * per, (rank + 1) * per
             rows, cols, rp, cj, va = G.stencil27(nx, ny, nz, row_begin=r0, row_end=r1)
+        elif kind == "blockdiag":               # no rank needs anything from another one
+            per = 50
+            total = per * world
+            r0, r1 = rank * per, (rank + 1) * per
+            rows, _, rp, cj, va = G.band(per, 3, seed=rank + 1)
+            cj = cj + r0
+            cols = total
         else:                                   # skewed rows, empty rows, long-range columns
             from spmv_amd.distributed import row_blocks_by_nnz, slice_row_block
             total = 90 * world
@@ -111,7 +118,7 @@ def test_row_blocks_by_nnz_balances_and_snaps():
 
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("exchange,kind", [("halo", "stencil"), ("allgather", "stencil"), ("halo", "powerlaw"),
-                                           ("allgather", "powerlaw"), ("halo", "powerlaw_nnz")])
+                                           ("allgather", "powerlaw"), ("halo", "powerlaw_nnz"), ("halo", "blockdiag")])
 def test_row_block_spmv_matches_single_process(orc, world, exchange, kind):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -125,6 +132,15 @@ def test_row_block_spmv_matches_single_process(orc, world, exchange, kind):
         assert p.exitcode == 0
     if kind == "stencil":
         rows, cols, rp, cj, va = G.stencil27(7, 6, 4 * world)
+    elif kind == "blockdiag":
+        blocks = [G.band(50, 3, seed=r + 1) for r in range(world)]
+        rows = cols = 50 * world
+        cj = torch.cat([b[3] + 50 * r for r, b in enumerate(blocks)])
+        va = torch.cat([b[4] for b in blocks])
+        counts = torch.cat([(b[2][1:] - b[2][:-1]) for b in blocks]).to(torch.int64)
+        rp = torch.zeros(rows + 1, dtype=torch.int64)
+        rp[1:] = torch.cumsum(counts, 0)
+        rp = rp.to(torch.int32)
     else:
         rows, cols, rp, cj, va = G.power_law_rows(90 * world, seed=9)
     g = torch.Generator().manual_seed(77)
