@@ -2,6 +2,8 @@
 runs of empty rows, single-entry rows, rectangular shapes, sizes off every block boundary) through
 every format of the C ABI against the CPU oracle's mult_csr_base (reference csr.c:4-13).
 Tolerances as in test_gpu_parity.py."""
+import os
+
 import numpy as np
 import pytest
 
@@ -11,7 +13,7 @@ from tests.util import bits_equal
 
 pytestmark = pytest.mark.gpu
 
-SEEDS = list(range(12))
+SEEDS = list(range(int(os.environ.get("SPMV_FUZZ_SEEDS", "12"))))   # more seeds for an occasional longer run
 
 
 def _random_csr(seed):
@@ -46,6 +48,10 @@ def test_every_format_on_random_shapes(orc, seed):
     want = orc.mult_csr_base(rp, cj, va, x)
     x32 = x.astype(np.float32)
     want32 = orc.mult_csr_base_f32(rp, cj, va.astype(np.float32), x32)
+    va32 = va.astype(np.float32).astype(np.float64)
+    exact32 = orc.mult_csr_base(rp, cj, va32, x32.astype(np.float64))            # fp64 product of the fp32 data
+    mag32 = orc.mult_csr_base(rp, cj, np.abs(va32), np.abs(x32).astype(np.float64))
+    bound32 = (np.diff(rp) + 1) * 2.0 ** -24 * mag32 * 1.01 + 1e-45
     coo = S.make_coo(np.repeat(np.arange(rows, dtype=np.int32), np.diff(rp)), cj, va)
     builders = {
         "csr_scalar": lambda dt: Matrix.csr(rows, cols, coo.copy(), 1, dt, S.CSR_SCALAR),
@@ -79,5 +85,9 @@ def test_every_format_on_random_shapes(orc, seed):
         if name in exact:
             assert bits_equal(y.astype(np.float32), want32), (name, seed)
         else:
-            assert orc.rel_l2(y, want32.astype(np.float64)) <= 2e-6, (name, seed)
+            # Any summation order of n fp32 products is within (n+1)·u·Σ|a·x| of the exact sum
+            # (u = 2^-24); the in-order fp32 result of the oracle carries the same error, so it
+            # is not the yardstick for rows of thousands of entries.
+            assert np.all(np.abs(y - exact32) <= bound32), (name, seed)
+            assert orc.rel_l2(y, want32.astype(np.float64)) <= 1e-5, (name, seed)
         m.free()
