@@ -183,6 +183,18 @@ int spmv_hip_mult(spmv_hip_matrix *m, const double *x, double *y);
  * (a hipStream_t; NULL = default stream).  Asynchronous. */
 int spmv_hip_mult_dev(spmv_hip_matrix *m, const void *d_x, void *d_y, void *stream);
 
+/* mult_mv_csr(struct csr *, int n, double *x, double *y) (spmv.h:54; declared
+ * there, defined nowhere in the reference): y_v = A * x_v for v = 0..n-1 with
+ * the matrix read once per block of up to 8 vectors.  Host form: vector v is
+ * x + v*columns, its result y + v*rows.  Works on a handle of any format;
+ * each result column is bit-identical to mult_csr_base (csr.c:4-13) of x_v. */
+int spmv_hip_mult_mv(spmv_hip_matrix *m, int n, const double *x, double *y);
+/* The same with the vector blocks resident in HBM (dtype elements): vector v
+ * at d_x + v*ldx (ldx >= columns), result at d_y + v*ldy (ldy >= rows).
+ * Asynchronous on `stream`. */
+int spmv_hip_mult_mv_dev(spmv_hip_matrix *m, int n, const void *d_x, int64_t ldx, void *d_y, int64_t ldy,
+                         void *stream);
+
 /* Row map for a CSR_SCALAR / CSR_VECTOR handle whose rows are a compacted
  * subset of a larger vector: row k writes y[d_row_map[k]] (device array of
  * `rows` ints, kept alive by the caller; NULL restores y[k]).  Used by the

@@ -57,6 +57,7 @@ def lib():
         "orc_csr_count": (C.c_int64, [C.c_int, C.c_int64, C.c_int, _coop]),
         "orc_csr_fill": (None, [C.c_int, C.c_int64, C.c_int, _coop, _i32p, _i32p, _f64p]),
         "orc_mult_csr_base": (None, [C.c_int, _i32p, _i32p, _f64p, _f64p, _f64p]),
+        "orc_mult_mv_csr": (None, [C.c_int, _i32p, _i32p, _f64p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
         "orc_mult_csr_base_f32": (None, [C.c_int, _i32p, _i32p, _f32p, _f32p, _f32p]),
         "orc_mult_csr_omp": (None, [C.c_int, _i32p, _i32p, _f64p, _f64p, _f64p]),
         "orc_merge_path_search": (None, [C.c_int, _i32p, C.c_int, C.c_int,
@@ -135,6 +136,14 @@ def mult_csr_base(rp, cj, va, x):
     y = np.empty(len(rp) - 1, np.float64)
     lib().orc_mult_csr_base(len(rp) - 1, rp, cj, va, x, y)
     return y
+
+
+def mult_mv_csr(rp, cj, va, X):
+    """X[n, columns] -> Y[n, rows]; n products of mult_csr_base."""
+    X = np.ascontiguousarray(X, np.float64)
+    Y = np.empty((X.shape[0], len(rp) - 1), np.float64)
+    lib().orc_mult_mv_csr(len(rp) - 1, rp, cj, va, X.shape[0], X.ctypes.data, X.shape[1], Y.ctypes.data, Y.shape[1])
+    return Y
 
 
 def mult_csr_base_f32(rp, cj, va32, x32):

@@ -139,6 +139,12 @@ void orc_mult_csr_base(int rows, const int *row_ptr, const int *col, const doubl
     }
 }
 
+void orc_mult_mv_csr(int rows, const int *row_ptr, const int *col, const double *val, int n,
+                     const double *x, int64_t ldx, double *y, int64_t ldy)
+{
+    for (int v = 0; v < n; v++) orc_mult_csr_base(rows, row_ptr, col, val, x + v * ldx, y + v * ldy);
+}
+
 void orc_mult_csr_base_f32(int rows, const int *row_ptr, const int *col, const float *val,
                            const float *x, float *y)
 {

@@ -47,6 +47,11 @@ void orc_csr_fill(int rows, int64_t nnz, int alignment, const orc_coo_t *coo,
 /* csr.c:4-13 */
 void orc_mult_csr_base(int rows, const int *row_ptr, const int *col, const double *val,
                        const double *x, double *y);
+/* mult_mv_csr(csr, n, x, y) -- declared at spmv.h:54, defined nowhere in the reference, so parity
+ * is unpinned by it.  Restated as n independent mult_csr_base products (csr.c:4-13): vector v is
+ * x + v*ldx, its result y + v*ldy. */
+void orc_mult_mv_csr(int rows, const int *row_ptr, const int *col, const double *val, int n,
+                     const double *x, int64_t ldx, double *y, int64_t ldy);
 /* fp32 restatement of csr.c:4-13 (float storage, float accumulate; unpinned) */
 void orc_mult_csr_base_f32(int rows, const int *row_ptr, const int *col, const float *val,
                            const float *x, float *y);

@@ -50,6 +50,8 @@ SIGNATURES = {
     "spmv_hip_create_auto_from_device_csr": (_vp, [_i, _i, _i64, _vp, _vp, _vp, _i, _i, _vp]),
     "spmv_hip_mult": (_i, [_vp, _vp, _vp]),
     "spmv_hip_mult_dev": (_i, [_vp, _vp, _vp, _vp]),
+    "spmv_hip_mult_mv": (_i, [_vp, _i, _vp, _vp]),
+    "spmv_hip_mult_mv_dev": (_i, [_vp, _i, _vp, C.c_int64, _vp, C.c_int64, _vp]),
     "spmv_hip_set_row_map": (_i, [_vp, _vp]),
     "spmv_hip_free": (_i, [_vp]),
     "spmv_hip_bench": (_i, [_vp, _i, C.c_double, _vp, C.POINTER(_i), C.POINTER(C.c_double)]),

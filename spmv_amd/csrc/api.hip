@@ -377,6 +377,49 @@ int spmv_hip_mult(spmv_hip_matrix *m, const double *x, double *y)
     return download_vector(m, m->d_y, y, m->rows);
 }
 
+int spmv_hip_mult_mv_dev(spmv_hip_matrix *m, int n, const void *d_x, int64_t ldx, void *d_y, int64_t ldy, void *stream)
+{
+    if (!m) { set_error("NULL handle"); return 1; }
+    if (n < 0) { set_error("mult_mv: negative vector count %d", n); return 1; }
+    if (n > 1 && (ldx < m->columns || ldy < m->rows)) {
+        set_error("mult_mv: ldx %lld / ldy %lld shorter than the vectors (%d columns, %d rows)", (long long)ldx,
+                  (long long)ldy, m->columns, m->rows);
+        return 1;
+    }
+    if (n > 0 && (!d_x || !d_y) && m->rows > 0) { set_error("mult_mv: NULL vector block"); return 1; }
+    return launch_mult_mv(m, n, d_x, ldx, d_y, ldy, (hipStream_t)stream);
+}
+
+int spmv_hip_mult_mv(spmv_hip_matrix *m, int n, const double *x, double *y)
+{
+    clear_error();
+    if (!m || !x || !y) { set_error("NULL argument"); return 1; }
+    if (n < 0) { set_error("mult_mv: negative vector count %d", n); return 1; }
+    if (m->d_row_map) { set_error("row-mapped handles multiply through spmv_hip_mult_mv_dev only"); return 1; }
+    if (n == 0) return 0;
+    const size_t es = dtype_size(m->dtype);
+    const size_t nx = (size_t)n * (size_t)m->columns, ny = (size_t)n * (size_t)m->rows;
+    char *dx = nullptr, *dy = nullptr;
+    int rc = 1;
+    do {
+        SPMV_HIP_TRY(hipMalloc((void **)&dx, std::max<size_t>(nx, 1) * es), break);
+        SPMV_HIP_TRY(hipMalloc((void **)&dy, std::max<size_t>(ny, 1) * es), break);
+        bool ok = true;
+        for (int v = 0; v < n && ok; v++)
+            ok = upload_vector(m, dx + (size_t)v * m->columns * es, x + (size_t)v * m->columns, m->columns) == 0;
+        if (!ok) break;
+        if (launch_mult_mv(m, n, dx, m->columns, dy, m->rows, nullptr)) break;
+        SPMV_HIP_TRY(hipDeviceSynchronize(), break);
+        for (int v = 0; v < n && ok; v++)
+            ok = download_vector(m, dy + (size_t)v * m->rows * es, y + (size_t)v * m->rows, m->rows) == 0;
+        if (!ok) break;
+        rc = 0;
+    } while (0);
+    if (dx) (void)hipFree(dx);
+    if (dy) (void)hipFree(dy);
+    return rc;
+}
+
 int spmv_hip_free(spmv_hip_matrix *m)
 {
     if (!m) return 0;

@@ -85,6 +85,9 @@ namespace spmv {
 
 // kernels.hip -- asynchronous launches on `stream`
 int launch_mult(const spmv_hip_matrix *m, const void *d_x, void *d_y, hipStream_t stream);
+// multivec.hip -- y_v = A x_v for n vectors spaced ldx / ldy elements apart
+int launch_mult_mv(const spmv_hip_matrix *m, int n, const void *d_x, int64_t ldx, void *d_y, int64_t ldy,
+                   hipStream_t stream);
 int variant_candidates(const spmv_hip_matrix *m, int *out, int max_out);
 int launch_norm2(int n, const void *d_x, int dtype, double *d_out, hipStream_t stream);
 int launch_scale(int n, const void *d_y, void *d_x, int dtype, const double *d_norm, hipStream_t stream);

@@ -1,0 +1,314 @@
+// Products with a block of vectors: y_v = A * x_v for v = 0..n-1, the operation the reference
+// declares as mult_mv_csr(struct csr *, int n, double *x, double *y) (src/spmv.h:54) and never
+// defines.  Vector v is the contiguous array x + v*ldx, its result y + v*ldy.
+//
+// The matrix is streamed once for NV vectors at a time (NV = 8, 4, 2, then 1 for an odd last
+// vector), so its 12 bytes per entry are shared by NV products.  Every
+// kernel here is lane-per-row with one fma per entry in ascending position, i.e. every column of
+// the result is bit-identical to mult_csr_base (reference csr.c:4-13) of that vector, whatever
+// the format of the handle:
+//   sliced formats of height 64 (SELL-C-sigma, SELLP, ELL)  -> sliced64_mv_kernel
+//   sliced formats of other heights                         -> sliced_any_mv_kernel
+//   SELL without padding                                    -> sell_dfc_mv_kernel
+//   CSR, merge-path CSR, balanced CSR (all hold plain CSR)  -> csr_rows_lds_mv_kernel
+
+#include "internal.h"
+#include "device_utils.h"
+
+namespace spmv {
+
+template <typename T, bool NT> __device__ __forceinline__ T stream_load(const T *p)
+{
+    return NT ? __builtin_nontemporal_load(p) : *p;
+}
+
+// One wave per slice, lane = row; U columns of the slice are loaded per batch and used for all NV
+// vectors before the next batch.
+template <typename T, bool PERM, int NV, int U, bool NT>
+__global__ __launch_bounds__(kBlock) void sliced64_mv_kernel(int rows, int nslices,
+                                                             const int64_t *__restrict__ slice_ptr,
+                                                             const int *__restrict__ row_order,
+                                                             const unsigned char *__restrict__ slice_ident,
+                                                             const int *__restrict__ scol,
+                                                             const T *__restrict__ sval,
+                                                             const T *__restrict__ x, int64_t ldx,
+                                                             T *__restrict__ y, int64_t ldy)
+{
+    unsigned b = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    int s = __builtin_amdgcn_readfirstlane((int)(b * (kBlock / kWave) + threadIdx.x / kWave));
+    if (s >= nslices) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t base = slice_ptr[s];
+    const int width = (int)((slice_ptr[s + 1] - base) >> 6);
+    const T *v = sval + base + lane;
+    const int *c = scol + base + lane;
+    T acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) acc[k] = 0;
+    int j = 0;
+    for (; j + U <= width; j += U) {
+        int cc[U];
+        T vv[U], xx[NV][U];
+#pragma unroll
+        for (int u = 0; u < U; u++) cc[u] = stream_load<int, NT>(c + (int64_t)(j + u) * kWave);
+#pragma unroll
+        for (int u = 0; u < U; u++) vv[u] = stream_load<T, NT>(v + (int64_t)(j + u) * kWave);
+#pragma unroll
+        for (int k = 0; k < NV; k++)
+#pragma unroll
+            for (int u = 0; u < U; u++) xx[k][u] = x[k * ldx + cc[u]];
+#pragma unroll
+        for (int k = 0; k < NV; k++)
+#pragma unroll
+            for (int u = 0; u < U; u++) acc[k] = fma_t(xx[k][u], vv[u], acc[k]);
+    }
+    for (; j < width; j++) {
+        const int cc = stream_load<int, NT>(c + (int64_t)j * kWave);
+        const T vv = stream_load<T, NT>(v + (int64_t)j * kWave);
+#pragma unroll
+        for (int k = 0; k < NV; k++) acc[k] = fma_t(x[k * ldx + cc], vv, acc[k]);
+    }
+    const int r = s * kWave + lane;
+    if (r < rows) {
+        const int dst = PERM && !slice_ident[s] ? row_order[r] : r;
+#pragma unroll
+        for (int k = 0; k < NV; k++) y[k * ldy + dst] = acc[k];
+    }
+}
+
+// Slice heights below 64 (the reference's CPU-shaped blocks): lane per row.
+template <typename T, bool PERM, int NV>
+__global__ __launch_bounds__(kBlock) void sliced_any_mv_kernel(int rows, int height,
+                                                               const int64_t *__restrict__ slice_ptr,
+                                                               const int *__restrict__ row_order,
+                                                               const int *__restrict__ scol,
+                                                               const T *__restrict__ sval,
+                                                               const T *__restrict__ x, int64_t ldx,
+                                                               T *__restrict__ y, int64_t ldy)
+{
+    unsigned b = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    int r = (int)(b * kBlock + threadIdx.x);
+    if (r >= rows) return;
+    const int s = r / height, k0 = r - s * height;
+    const int64_t base = slice_ptr[s];
+    const int width = (int)((slice_ptr[s + 1] - base) / height);
+    T acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) acc[k] = 0;
+    for (int j = 0; j < width; j++) {
+        const int64_t at = base + (int64_t)j * height + k0;
+        const int cc = scol[at];
+        const T vv = sval[at];
+#pragma unroll
+        for (int k = 0; k < NV; k++) acc[k] = fma_t(x[k * ldx + cc], vv, acc[k]);
+    }
+    const int dst = PERM ? row_order[r] : r;
+#pragma unroll
+    for (int k = 0; k < NV; k++) y[k * ldy + dst] = acc[k];
+}
+
+// SELL-C-sigma without padding: column j of a slice holds the rows longer than j, which are lanes
+// 0..active-1 because the slice's rows are sorted by length (reference sellcs_format.c:53-136).
+// The start of each column is carried as a wave-uniform counter.
+template <typename T, int NV, int U, bool NT>
+__global__ __launch_bounds__(kBlock) void sell_dfc_mv_kernel(int rows, int nslices,
+                                                             const int64_t *__restrict__ slice_ptr,
+                                                             const int *__restrict__ sorted_len,
+                                                             const int *__restrict__ row_order,
+                                                             const int *__restrict__ scol,
+                                                             const T *__restrict__ sval,
+                                                             const T *__restrict__ x, int64_t ldx,
+                                                             T *__restrict__ y, int64_t ldy)
+{
+    unsigned b = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    int s = __builtin_amdgcn_readfirstlane((int)(b * (kBlock / kWave) + threadIdx.x / kWave));
+    if (s >= nslices) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int r = s * kWave + lane;
+    const int len = r < rows ? sorted_len[r] : 0;
+    const int width = __builtin_amdgcn_readfirstlane(len);
+    const int *c = scol + slice_ptr[s] + lane;
+    const T *v = sval + slice_ptr[s] + lane;
+    int run = 0;
+    T acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) acc[k] = 0;
+    for (int j0 = 0; j0 < width; j0 += U) {
+        int off[U], cc[U];
+        T vv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            off[u] = run;
+            run += __popcll(__ballot(j0 + u < len));
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) cc[u] = j0 + u < len ? stream_load<int, NT>(c + off[u]) : 0;
+#pragma unroll
+        for (int u = 0; u < U; u++) vv[u] = j0 + u < len ? stream_load<T, NT>(v + off[u]) : (T)0;
+#pragma unroll
+        for (int k = 0; k < NV; k++)
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const T xv = x[k * ldx + cc[u]];
+                if (j0 + u < len) acc[k] = fma_t(xv, vv[u], acc[k]);
+            }
+    }
+    if (r < rows) {
+        const int dst = row_order[r];
+#pragma unroll
+        for (int k = 0; k < NV; k++) y[k * ldy + dst] = acc[k];
+    }
+}
+
+// Plain CSR, lane per row, the matrix stream staged through LDS: a 64-lane workgroup owns 64
+// consecutive rows = one contiguous run of the column and value arrays, walks it in line-aligned
+// chunks of 64*IPL entries with full-width loads, gathers the NV x values of every entry there and
+// parks (value, x_0..x_NV-1) in LDS, from where each lane adds the part of its own row that lies in
+// the chunk.
+template <typename T, int NV> struct mv_entry { T v; T x[NV]; };
+
+template <typename T, int IPL, int NV, bool NT>
+__global__ __launch_bounds__(kWave) void csr_rows_lds_mv_kernel(int rows, const int *__restrict__ row_ptr,
+                                                                const int *__restrict__ col,
+                                                                const T *__restrict__ val,
+                                                                const int *__restrict__ row_map,
+                                                                const T *__restrict__ x, int64_t ldx,
+                                                                T *__restrict__ y, int64_t ldy)
+{
+    constexpr int kCap = kWave * IPL;
+    __shared__ mv_entry<T, NV> stage[kCap];
+    const int blk = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int lane = threadIdx.x;
+    const int row = blk * kWave + lane;
+    const int last = min(blk * kWave + kWave, rows);
+    const int rs = row_ptr[min(row, rows)];
+    const int re = row < rows ? row_ptr[row + 1] : rs;
+    const int run_begin = __builtin_amdgcn_readfirstlane(rs);
+    const int run_end = row_ptr[last];
+    T acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) acc[k] = 0;
+    for (int e0 = run_begin & ~31; e0 < run_end; e0 += kCap) {
+        int cc[IPL];
+        T vv[IPL];
+#pragma unroll
+        for (int i = 0; i < IPL; i++)
+            cc[i] = stream_load<int, NT>(col + min(max(e0 + lane + i * kWave, run_begin), run_end - 1));
+#pragma unroll
+        for (int i = 0; i < IPL; i++)
+            vv[i] = stream_load<T, NT>(val + min(max(e0 + lane + i * kWave, run_begin), run_end - 1));
+#pragma unroll
+        for (int i = 0; i < IPL; i++) {
+            mv_entry<T, NV> e;
+            e.v = vv[i];
+#pragma unroll
+            for (int k = 0; k < NV; k++) e.x[k] = x[k * ldx + cc[i]];
+            stage[lane + i * kWave] = e;
+        }
+        __syncthreads();
+        const int kend = min(re, min(e0 + kCap, run_end)) - e0;
+        for (int p = max(rs, e0) - e0; p < kend; p++) {
+            const mv_entry<T, NV> e = stage[p];
+#pragma unroll
+            for (int k = 0; k < NV; k++) acc[k] = fma_t(e.x[k], e.v, acc[k]);
+        }
+        __syncthreads();
+    }
+    if (row < rows) {
+        const int dst = row_map ? row_map[row] : row;
+#pragma unroll
+        for (int k = 0; k < NV; k++) y[k * ldy + dst] = acc[k];
+    }
+}
+
+// ------------------------------------------------------------------ launchers --
+
+static inline unsigned blocks_for(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+template <typename T, int NV, bool NT>
+static int launch_block(const spmv_hip_matrix *m, const T *x, int64_t ldx, T *y, int64_t ldy, hipStream_t st)
+{
+    constexpr int U = NV >= 8 ? 2 : (NV == 4 ? 4 : 8);
+    switch (m->format) {
+    case SPMV_HIP_CSR_SCALAR:
+    case SPMV_HIP_CSR_VECTOR:
+    case SPMV_HIP_CSR_MERGE:
+    case SPMV_HIP_CSR_BAL:
+        hipLaunchKernelGGL((csr_rows_lds_mv_kernel<T, 4, NV, NT>), dim3(blocks_for(m->rows, kWave)), dim3(kWave), 0, st,
+                           m->rows, m->d_row_ptr, m->d_col, (const T *)m->d_val, m->d_row_map, x, ldx, y, ldy);
+        break;
+    case SPMV_HIP_SELL:
+    case SPMV_HIP_SELLP:
+    case SPMV_HIP_ELL: {
+        const bool perm = m->d_row_order != nullptr;
+        const T *sv = (const T *)m->d_sval;
+        if (m->slice_height == kWave) {
+            const dim3 grid(blocks_for(m->nslices, kBlock / kWave)), block(kBlock);
+            if (perm)
+                hipLaunchKernelGGL((sliced64_mv_kernel<T, true, NV, U, NT>), grid, block, 0, st, m->rows, m->nslices,
+                                   m->d_slice_ptr, m->d_row_order, m->d_slice_ident, m->d_scol, sv, x, ldx, y, ldy);
+            else
+                hipLaunchKernelGGL((sliced64_mv_kernel<T, false, NV, U, NT>), grid, block, 0, st, m->rows, m->nslices,
+                                   m->d_slice_ptr, m->d_row_order, m->d_slice_ident, m->d_scol, sv, x, ldx, y, ldy);
+        } else {
+            const dim3 grid(blocks_for(m->rows, kBlock)), block(kBlock);
+            if (perm)
+                hipLaunchKernelGGL((sliced_any_mv_kernel<T, true, NV>), grid, block, 0, st, m->rows, m->slice_height,
+                                   m->d_slice_ptr, m->d_row_order, m->d_scol, sv, x, ldx, y, ldy);
+            else
+                hipLaunchKernelGGL((sliced_any_mv_kernel<T, false, NV>), grid, block, 0, st, m->rows, m->slice_height,
+                                   m->d_slice_ptr, m->d_row_order, m->d_scol, sv, x, ldx, y, ldy);
+        }
+        break;
+    }
+    case SPMV_HIP_SELL_DFC:
+        hipLaunchKernelGGL((sell_dfc_mv_kernel<T, NV, (NV >= 8 ? 2 : 4), NT>), dim3(blocks_for(m->nslices, kBlock / kWave)),
+                           dim3(kBlock), 0, st, m->rows, m->nslices, m->d_slice_ptr, m->d_sorted_len, m->d_row_order,
+                           m->d_scol, (const T *)m->d_sval, x, ldx, y, ldy);
+        break;
+    default: set_error("unknown format %d", m->format); return 1;
+    }
+    return 0;
+}
+
+template <typename T>
+static int launch_mult_mv_t(const spmv_hip_matrix *m, int n, const T *x, int64_t ldx, T *y, int64_t ldy, hipStream_t st)
+{
+    if (m->rows == 0 || n == 0) return 0;
+    // matrices far larger than the caches are streamed with non-temporal loads
+    const bool nt = m->stored * (int64_t)(sizeof(T) + 4) > ((int64_t)512 << 20);
+    int v = 0;
+    while (v < n) {
+        const int left = n - v;
+        const T *xv = x + (int64_t)v * ldx;
+        T *yv = y + (int64_t)v * ldy;
+        int rc, took;
+        if (left >= 8) {
+            took = 8;
+            rc = nt ? launch_block<T, 8, true>(m, xv, ldx, yv, ldy, st) : launch_block<T, 8, false>(m, xv, ldx, yv, ldy, st);
+        } else if (left >= 4) {
+            took = 4;
+            rc = nt ? launch_block<T, 4, true>(m, xv, ldx, yv, ldy, st) : launch_block<T, 4, false>(m, xv, ldx, yv, ldy, st);
+        } else if (left >= 2) {
+            took = 2;
+            rc = nt ? launch_block<T, 2, true>(m, xv, ldx, yv, ldy, st) : launch_block<T, 2, false>(m, xv, ldx, yv, ldy, st);
+        } else {
+            took = 1;
+            rc = nt ? launch_block<T, 1, true>(m, xv, ldx, yv, ldy, st) : launch_block<T, 1, false>(m, xv, ldx, yv, ldy, st);
+        }
+        if (rc) return rc;
+        v += took;
+    }
+    SPMV_HIP_TRY(hipGetLastError(), return 1);
+    return 0;
+}
+
+int launch_mult_mv(const spmv_hip_matrix *m, int n, const void *d_x, int64_t ldx, void *d_y, int64_t ldy,
+                   hipStream_t stream)
+{
+    if (m->dtype == SPMV_HIP_F32)
+        return launch_mult_mv_t<float>(m, n, (const float *)d_x, ldx, (float *)d_y, ldy, stream);
+    return launch_mult_mv_t<double>(m, n, (const double *)d_x, ldx, (double *)d_y, ldy, stream);
+}
+
+} // namespace spmv

@@ -120,6 +120,19 @@ class Matrix:
     def mult_dev(self, d_x: int, d_y: int, stream: int = 0) -> None:
         L.check(L.lib().spmv_hip_mult_dev(self._h, d_x, d_y, stream))
 
+    def mult_mv(self, x: np.ndarray) -> np.ndarray:
+        """mult_mv_csr(csr, n, x, y) (spmv.h:54): x[n, columns] -> y[n, rows], one product per row of x."""
+        info = self.info
+        x = np.ascontiguousarray(x, np.float64)
+        if x.ndim != 2 or x.shape[1] != info.columns:
+            raise ValueError(f"x has shape {x.shape}, expected (n, {info.columns})")
+        y = np.full((x.shape[0], info.rows), np.nan)
+        L.check(L.lib().spmv_hip_mult_mv(self._h, x.shape[0], _ptr(x), _ptr(y)))
+        return y
+
+    def mult_mv_dev(self, n: int, d_x: int, ldx: int, d_y: int, ldy: int, stream: int = 0) -> None:
+        L.check(L.lib().spmv_hip_mult_mv_dev(self._h, n, d_x, ldx, d_y, ldy, stream))
+
     def bench(self, x: np.ndarray, min_iters=10, min_seconds=2.0):
         """The driver's timed power loop (driver_spmv.c:292-308) -> (iters, seconds, GFLOP/s, x_last)."""
         x = np.ascontiguousarray(x, np.float64).copy()
