@@ -75,6 +75,7 @@ typedef struct spmv_hip_info {
     int     items_per_tile;
     int64_t device_bytes; /* HBM held by the handle                                   */
     int     variant;      /* kernel variant in use (spmv_hip_set_option / spmv_hip_analyze) */
+    int     hot_columns;  /* 1 = columns relabeled by reference count (option "hot_columns") */
 } spmv_hip_info;
 
 /* Selects the device for subsequent creators on this thread (hipSetDevice). */
@@ -220,8 +221,17 @@ int spmv_hip_norm2_dev(int n, const void *d_x, int dtype, double *d_out, void *s
 int spmv_hip_scale_dev(int n, const void *d_y, void *d_x, int dtype, const double *d_norm, void *stream);
 
 /* ---- tuning (counterpart of sellcs_analyze_matrix, sellcs_analyzer.c:46-120:
- * pick the launch shape by trial).  Options: "variant" = kernel variant of the
- * handle's format (0 = default). */
+ * pick the launch shape by trial).  Options:
+ *  "variant" = kernel variant of the handle's format (0 = default);
+ *  "hot_columns" = 1: CSR-based handles (scalar, vector, merge, balanced) keep a
+ *    second column array whose labels number the columns in descending order
+ *    of their reference count, and every product first permutes x to match, so
+ *    that the few columns a power-law matrix references most sit in one
+ *    cache-resident range of x.  Entry order inside the rows is untouched: y is
+ *    bit-identical to the product without the option.  Costs 4 bytes per stored
+ *    entry plus (4 + V) bytes per column of HBM and one pass over x per
+ *    product; products on one handle must then not overlap (they share the
+ *    permuted x).  0 drops the arrays again.  spmv_hip_mult_mv ignores it. */
 int spmv_hip_set_option(spmv_hip_matrix *m, const char *name, int64_t value);
 /* sellcs_analyze_matrix (sell.c:30, sellcs_analyzer.c:46-120) re-thought for the
  * GPU: times every kernel variant of the handle's format `reps` times on a

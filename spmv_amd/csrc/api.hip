@@ -426,7 +426,7 @@ int spmv_hip_free(spmv_hip_matrix *m)
     release_csr(m);
     void *ptrs[] = {m->d_tile_coord, m->d_row_carry, m->d_val_carry, m->d_nzr_id, m->d_nzr_end, m->d_slice_ptr,
                     m->d_row_order, m->d_slice_ident, m->d_scol, m->d_sval, m->d_sorted_len, m->d_vop_ptr, m->d_vop_len,
-                    m->d_x, m->d_y, m->d_norm};
+                    m->d_x, m->d_y, m->d_norm, m->d_hot_col, m->d_hot_old, m->d_hot_x};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete m;
@@ -480,11 +480,29 @@ int spmv_hip_scale_dev(int n, const void *d_y, void *d_x, int dtype, const doubl
     return launch_scale(n, d_y, d_x, dtype, d_norm, (hipStream_t)stream);
 }
 
+static void drop_hot_columns(spmv_hip_matrix *m)
+{
+    if (!m->d_hot_col) return;
+    m->device_bytes -= (int64_t)sizeof(int) * ((int64_t)m->columns + m->stored) + (int64_t)m->columns * (int64_t)dtype_size(m->dtype);
+    (void)hipFree(m->d_hot_col); (void)hipFree(m->d_hot_old); (void)hipFree(m->d_hot_x);
+    m->d_hot_col = nullptr; m->d_hot_old = nullptr; m->d_hot_x = nullptr;
+}
+
 int spmv_hip_set_option(spmv_hip_matrix *m, const char *name, int64_t value)
 {
     clear_error();
     if (!m || !name) { set_error("NULL argument"); return 1; }
     if (!strcmp(name, "variant")) { m->variant = (int)value; return 0; }
+    if (!strcmp(name, "hot_columns")) {
+        if (value == 0) { drop_hot_columns(m); return 0; }
+        if (m->d_hot_col) return 0;
+        if (m->format != SPMV_HIP_CSR_SCALAR && m->format != SPMV_HIP_CSR_VECTOR && m->format != SPMV_HIP_CSR_MERGE &&
+            m->format != SPMV_HIP_CSR_BAL) {
+            set_error("hot_columns needs a CSR-based format (scalar, vector, merge, balanced)");
+            return 1;
+        }
+        return build_hot_columns(m, nullptr);
+    }
     set_error("unknown option '%s'", name);
     return 1;
 }
@@ -559,6 +577,7 @@ int spmv_hip_analyze(spmv_hip_matrix *m, int reps)
 // would store more than kAutoMaxPadding times the non-zeros.
 static const int kAutoFormats[] = {SPMV_HIP_CSR_MERGE, SPMV_HIP_CSR_SCALAR, SPMV_HIP_CSR_VECTOR, SPMV_HIP_SELLP, SPMV_HIP_SELL};
 constexpr double kAutoMaxPadding = 2.0;
+constexpr int64_t kHotColumnsMinBytes = (int64_t)4 << 20;   // the L2 of one XCD
 
 static spmv_hip_matrix *view_of_device_csr(int format, int rows, int columns, int64_t nnz, const int *d_row_ptr,
                                            const int *d_col, const void *d_val, int dtype, hipStream_t st)
@@ -595,6 +614,21 @@ static spmv_hip_matrix *auto_from_device_csr(int rows, int columns, int64_t nnz,
             best = m; best_ms = ms;
         } else {
             spmv_hip_free(m);
+        }
+    }
+    // a CSR-based winner whose x does not fit one L2: try the columns relabeled by reference count
+    // (pays on power-law column counts, costs a pass over x otherwise) and keep it if clearly faster
+    const bool csr_based = best && (best->format == SPMV_HIP_CSR_MERGE || best->format == SPMV_HIP_CSR_SCALAR ||
+                                    best->format == SPMV_HIP_CSR_VECTOR || best->format == SPMV_HIP_CSR_BAL);
+    if (csr_based && (int64_t)columns * (int64_t)dtype_size(dtype) > kHotColumnsMinBytes && nnz > 0) {
+        const int keep_variant = best->variant, keep_lanes = best->lanes_per_row;
+        float ms = 0;
+        if (build_hot_columns(best, st) == 0 && analyze_impl(best, reps, &ms) == 0 && ms < 0.95f * best_ms) {
+            best_ms = ms;
+        } else {
+            drop_hot_columns(best);
+            best->variant = keep_variant;
+            best->lanes_per_row = keep_lanes;
         }
     }
     if (best) {
@@ -647,6 +681,7 @@ int spmv_hip_get_info(const spmv_hip_matrix *m, spmv_hip_info *info)
     info->ntiles = m->ntiles; info->items_per_tile = m->items_per_tile;
     info->device_bytes = m->device_bytes;
     info->variant = m->variant;
+    info->hot_columns = m->d_hot_col != nullptr;
     return 0;
 }
 

@@ -74,6 +74,12 @@ struct spmv_hip_matrix {
     uint8_t *d_vop_len = nullptr;   // vops
     int64_t vops = 0;
 
+    // columns relabeled by reference count (option "hot_columns", CSR-based formats): the col array with
+    // the new labels, the column of x behind each label, and the permuted copy of x the kernels read
+    int *d_hot_col = nullptr;
+    int *d_hot_old = nullptr;
+    void *d_hot_x = nullptr;
+
     // staging vectors for the host-pointer multiply and the bench loop
     void *d_x = nullptr, *d_y = nullptr;
     double *d_norm = nullptr;
@@ -96,6 +102,7 @@ int launch_scale(int n, const void *d_y, void *d_x, int dtype, const double *d_n
 // `val_is_f64`: element type of d_val (host creators upload doubles; the device
 // creator hands over dtype elements).
 int choose_lanes_per_row(int rows, int64_t stored);
+int build_hot_columns(spmv_hip_matrix *m, hipStream_t stream);                            // sort.hip
 int device_exclusive_scan(const int *d_in, int *d_out, size_t n, hipStream_t stream);   // sort.hip (rocPRIM)
 int device_coo_to_csr(int rows, int columns, int64_t nnz, struct mtx *coo, bool values_f64, int **d_row_ptr,
                       int **d_col, void **d_val);                                         // sort.hip

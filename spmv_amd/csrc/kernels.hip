@@ -1030,8 +1030,31 @@ template <typename T> static int launch_mult_t(const spmv_hip_matrix *m, const T
     return 0;
 }
 
+// xh[k] = x[old_of_new[k]]: x under the column labels of the "hot_columns" option
+template <typename T>
+__global__ __launch_bounds__(kBlock) void permute_x_kernel(int n, const int *__restrict__ old_of_new,
+                                                           const T *__restrict__ x, T *__restrict__ xh)
+{
+    int k = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (k < n) xh[k] = x[old_of_new[k]];
+}
+
 int launch_mult(const spmv_hip_matrix *m, const void *d_x, void *d_y, hipStream_t stream)
 {
+    if (m->d_hot_col && m->rows > 0) {
+        // permute x, then run the format's kernel on the relabeled column array
+        const dim3 grid(cdiv(m->columns, kBlock)), block(kBlock);
+        if (m->dtype == SPMV_HIP_F32)
+            hipLaunchKernelGGL((permute_x_kernel<float>), grid, block, 0, stream, m->columns, m->d_hot_old,
+                               (const float *)d_x, (float *)m->d_hot_x);
+        else
+            hipLaunchKernelGGL((permute_x_kernel<double>), grid, block, 0, stream, m->columns, m->d_hot_old,
+                               (const double *)d_x, (double *)m->d_hot_x);
+        spmv_hip_matrix view = *m;
+        view.d_col = m->d_hot_col;
+        view.d_hot_col = nullptr;
+        return launch_mult(&view, m->d_hot_x, d_y, stream);
+    }
     if (m->dtype == SPMV_HIP_F32) return launch_mult_t<float>(m, (const float *)d_x, (float *)d_y, stream);
     return launch_mult_t<double>(m, (const double *)d_x, (double *)d_y, stream);
 }

@@ -197,6 +197,86 @@ int device_exclusive_scan(const int *d_in, int *d_out, size_t n, hipStream_t st)
     return rc;
 }
 
+// ---- columns relabeled by how often the matrix references them ----
+//
+// Every gather of x that misses the L2 costs a 128-byte request to the fabric whatever the size of
+// the element, and on matrices with power-law column counts (graphs, circuits) a few hundred thousand
+// columns take most of the references while lying scattered over the whole index range.  Numbering
+// the columns in descending order of their reference count packs those into the first megabytes of a
+// permuted copy of x, which then stay in L2.  The entries keep their places in the rows, so every
+// row is summed in the same order as before and the product is bit-identical to the one without
+// relabeling.
+
+__global__ void column_count_kernel(int64_t n, const int *__restrict__ col, unsigned *__restrict__ count)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) atomicAdd(&count[col[k]], 1u);
+}
+
+__global__ void iota_kernel(int n, int *__restrict__ out)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = k;
+}
+
+__global__ void invert_permutation_kernel(int n, const int *__restrict__ old_of_new, int *__restrict__ new_of_old)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) new_of_old[old_of_new[k]] = k;
+}
+
+__global__ void relabel_columns_kernel(int64_t n, const int *__restrict__ col, const int *__restrict__ new_of_old,
+                                       int *__restrict__ out)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = new_of_old[col[k]];
+}
+
+// Fills m->d_hot_old (column of x behind each new label), m->d_hot_col (the col array relabeled) and
+// m->d_hot_x (room for the permuted x).  0 on success; on failure nothing is left allocated.
+int build_hot_columns(spmv_hip_matrix *m, hipStream_t st)
+{
+    const int cols = m->columns;
+    const int64_t n = m->stored;
+    unsigned *d_count[2] = {nullptr, nullptr};
+    int *d_id = nullptr, *d_new_of_old = nullptr;
+    void *d_temp = nullptr;
+    int *hot_old = nullptr, *hot_col = nullptr;
+    char *hot_x = nullptr;
+    int64_t bytes_before = m->device_bytes;
+    int rc = 1;
+    do {
+        if (cols <= 0 || n <= 0) { set_error("hot_columns: empty matrix"); break; }
+        const size_t c = (size_t)cols;
+        SPMV_HIP_TRY(hipMalloc((void **)&d_count[0], c * sizeof(unsigned)), break);
+        SPMV_HIP_TRY(hipMalloc((void **)&d_count[1], c * sizeof(unsigned)), break);
+        SPMV_HIP_TRY(hipMalloc((void **)&d_id, c * sizeof(int)), break);
+        SPMV_HIP_TRY(hipMalloc((void **)&d_new_of_old, c * sizeof(int)), break);
+        if (dev_alloc(m, &hot_old, c) || dev_alloc(m, &hot_col, (size_t)n) || dev_alloc(m, &hot_x, c * dtype_size(m->dtype))) break;
+        const dim3 block(256), gcol((unsigned)((c + 255) / 256)), gnz((unsigned)((n + 255) / 256));
+        SPMV_HIP_TRY(hipMemsetAsync(d_count[0], 0, c * sizeof(unsigned), st), break);
+        hipLaunchKernelGGL(column_count_kernel, gnz, block, 0, st, n, m->d_col, d_count[0]);
+        hipLaunchKernelGGL(iota_kernel, gcol, block, 0, st, cols, d_id);
+        // stable descending sort: columns with equal counts keep their ascending order
+        size_t temp_bytes = 0;
+        SPMV_HIP_TRY(rocprim::radix_sort_pairs_desc(nullptr, temp_bytes, d_count[0], d_count[1], d_id, hot_old, c, 0, 32, st), break);
+        SPMV_HIP_TRY(hipMalloc(&d_temp, std::max<size_t>(temp_bytes, 16)), break);
+        SPMV_HIP_TRY(rocprim::radix_sort_pairs_desc(d_temp, temp_bytes, d_count[0], d_count[1], d_id, hot_old, c, 0, 32, st), break);
+        hipLaunchKernelGGL(invert_permutation_kernel, gcol, block, 0, st, cols, hot_old, d_new_of_old);
+        hipLaunchKernelGGL(relabel_columns_kernel, gnz, block, 0, st, n, m->d_col, d_new_of_old, hot_col);
+        SPMV_HIP_TRY(hipGetLastError(), break);
+        SPMV_HIP_TRY(hipStreamSynchronize(st), break);
+        m->d_hot_old = hot_old; m->d_hot_col = hot_col; m->d_hot_x = hot_x;
+        hot_old = nullptr; hot_col = nullptr; hot_x = nullptr;
+        rc = 0;
+    } while (0);
+    void *scratch[] = {d_count[0], d_count[1], d_id, d_new_of_old, d_temp, hot_old, hot_col, hot_x};
+    for (void *p : scratch)
+        if (p) (void)hipFree(p);
+    if (rc) m->device_bytes = bytes_before;
+    return rc;
+}
+
 } // namespace spmv
 
 // C-linkage hook for the host-only ingest file (mtxio.cpp is compiled without HIP headers)

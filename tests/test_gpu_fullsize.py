@@ -118,6 +118,11 @@ def test_c3_rmat_scale26_kernels_agree():
             assert _rel(_mult(m, 2.0 * x - 3.0 * z, rows), 2.0 * y - 3.0 * _mult(m, z, rows)) <= 1e-13
             m.set_option("variant", 1)
             assert _rel(_mult(m, x, rows), y_ref) <= 1e-13
+        if fmt in (S.CSR_MERGE, S.CSR_BAL):                            # columns relabeled by reference count
+            y_plain = _mult(m, x, rows)
+            m.set_option("hot_columns", 1)
+            assert torch.equal(_mult(m, x, rows), y_plain)
+            del y_plain
         m.free()
         del y
         torch.cuda.empty_cache()

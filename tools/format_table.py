@@ -50,13 +50,15 @@ def main():
         x = torch.rand(cols, dtype=td, device=dev, generator=g)
         y = torch.empty(rows, dtype=td, device=dev)
         for name in args.formats.split(","):
-            fmt, p0, p1 = FORMATS[name]
+            fmt, p0, p1 = FORMATS[name.split("+")[0]]       # "csr_merge+hot": with the hot_columns option
             try:
                 m = Matrix.from_device_csr(fmt, rows, cols, nnz, rp.data_ptr(), cj.data_ptr(), vals.data_ptr(), dtype,
                                            p0, p1, st)
             except S.SpmvHipError as e:
                 print(f"| {name} | {dname} | - | failed: {str(e)[:60]} | | | | |", flush=True)
                 continue
+            if name.endswith("+hot"):
+                m.set_option("hot_columns", 1)
             m.analyze(3)
             info = m.info
             variant = f"{info.lanes_per_row} lanes, {info.variant}" if fmt == S.CSR_VECTOR else str(info.variant)

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <algorithm>
 
@@ -60,13 +61,20 @@ template <int MODE> static void run(const double *table, size_t mask, double *ou
            gathers / ts[2] / 1e6);
 }
 
-int main()
+int main(int argc, char **argv)
 {
     const size_t n = (size_t)1 << 27;               // 1 GiB of doubles: beyond L2 and the 256 MiB cache
     double *table, *out;
     CK(hipMalloc(&table, n * 8)); CK(hipMalloc(&out, 8));
     CK(hipMemset(table, 0, n * 8));
     const size_t gathers = (size_t)1 << 28;
+    if (argc > 1 && !strcmp(argv[1], "sizes")) {    // the gather rate against the size of the table
+        for (int lg = 17; lg <= 27; lg++) {
+            printf("table %7.1f MiB: ", (double)((size_t)8 << lg) / (1 << 20));
+            run<0>(table, ((size_t)1 << lg) - 1, out, gathers);
+        }
+        return 0;
+    }
     run<0>(table, n - 1, out, gathers); run<1>(table, n - 1, out, gathers); run<2>(table, n - 1, out, gathers);
     run<3>(table, n - 1, out, gathers); run<4>(table, n - 1, out, gathers); run<5>(table, n - 1, out, gathers);
     run<6>(table, n - 1, out, gathers); run<7>(table, n - 1, out, gathers);
