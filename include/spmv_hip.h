@@ -75,7 +75,7 @@ typedef struct spmv_hip_info {
     int     items_per_tile;
     int64_t device_bytes; /* HBM held by the handle                                   */
     int     variant;      /* kernel variant in use (spmv_hip_set_option / spmv_hip_analyze) */
-    int     hot_columns;  /* 1 = columns relabeled by reference count (option "hot_columns") */
+    int     hot_columns;  /* option "hot_columns": 0 off, 1 columns relabeled by reference count, 2 dealt over the XCDs */
 } spmv_hip_info;
 
 /* Selects the device for subsequent creators on this thread (hipSetDevice). */
@@ -231,7 +231,15 @@ int spmv_hip_scale_dev(int n, const void *d_y, void *d_x, int dtype, const doubl
  *    bit-identical to the product without the option.  Costs 4 bytes per stored
  *    entry plus (4 + V) bytes per column of HBM and one pass over x per
  *    product; products on one handle must then not overlap (they share the
- *    permuted x).  0 drops the arrays again.  spmv_hip_mult_mv ignores it. */
+ *    permuted x).  0 drops the arrays again.  spmv_hip_mult_mv ignores it.
+ *    = 2: the ranking is dealt over the 8 XCDs instead, and the handle keeps a
+ *    second copy of the matrix split by column group (one group per XCD, so
+ *    the eight L2s hold eight different sets of hot columns) plus 8 partial
+ *    results per row that a last pass adds in group order: y then differs
+ *    from the plain product by reassociation (tolerance parity).  Costs
+ *    (4 + V) bytes per entry plus (36 + 8 V) bytes per row of HBM; pays once x
+ *    is far larger than the eight L2s together (R-MAT scale 26: 20.1 ms
+ *    plain, 12.0 ms with 1, 9.7 ms with 2). */
 int spmv_hip_set_option(spmv_hip_matrix *m, const char *name, int64_t value);
 /* sellcs_analyze_matrix (sell.c:30, sellcs_analyzer.c:46-120) re-thought for the
  * GPU: times every kernel variant of the handle's format `reps` times on a

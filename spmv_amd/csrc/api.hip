@@ -426,7 +426,8 @@ int spmv_hip_free(spmv_hip_matrix *m)
     release_csr(m);
     void *ptrs[] = {m->d_tile_coord, m->d_row_carry, m->d_val_carry, m->d_nzr_id, m->d_nzr_end, m->d_slice_ptr,
                     m->d_row_order, m->d_slice_ident, m->d_scol, m->d_sval, m->d_sorted_len, m->d_vop_ptr, m->d_vop_len,
-                    m->d_x, m->d_y, m->d_norm, m->d_hot_col, m->d_hot_old, m->d_hot_x};
+                    m->d_x, m->d_y, m->d_norm, m->d_hot_col, m->d_hot_old, m->d_hot_x, m->d_xcd_y};
+    if (m->xcd_sub) spmv_hip_free(m->xcd_sub);
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete m;
@@ -482,10 +483,54 @@ int spmv_hip_scale_dev(int n, const void *d_y, void *d_x, int dtype, const doubl
 
 static void drop_hot_columns(spmv_hip_matrix *m)
 {
+    if (m->xcd_sub) {
+        m->device_bytes -= m->xcd_bytes;
+        m->xcd_bytes = 0;
+        spmv_hip_free(m->xcd_sub);
+        (void)hipFree(m->d_hot_old); (void)hipFree(m->d_hot_x); (void)hipFree(m->d_xcd_y);
+        m->xcd_sub = nullptr; m->d_hot_old = nullptr; m->d_hot_x = nullptr; m->d_xcd_y = nullptr; m->xcd_cpx = 0;
+        return;
+    }
     if (!m->d_hot_col) return;
     m->device_bytes -= (int64_t)sizeof(int) * ((int64_t)m->columns + m->stored) + (int64_t)m->columns * (int64_t)dtype_size(m->dtype);
     (void)hipFree(m->d_hot_col); (void)hipFree(m->d_hot_old); (void)hipFree(m->d_hot_x);
     m->d_hot_col = nullptr; m->d_hot_old = nullptr; m->d_hot_x = nullptr;
+}
+
+// "hot_columns" = 2: stack the eight column groups into one balanced-CSR handle of 8*rows virtual rows
+static int build_xcd_split(spmv_hip_matrix *m, hipStream_t st)
+{
+    if (m->d_row_map) { set_error("hot_columns 2 does not combine with a row map"); return 1; }
+    int *vrp = nullptr, *vcol = nullptr, *old_of_label = nullptr, cpx = 0;
+    void *vval = nullptr;
+    if (build_xcd_columns(m, m->dtype == SPMV_HIP_F64, st, &vrp, &vcol, &vval, &old_of_label, &cpx)) return 1;
+    const int64_t es = (int64_t)dtype_size(m->dtype), labels = 8 * (int64_t)cpx;
+    spmv_hip_matrix *sub = new_handle(SPMV_HIP_CSR_BAL, m->dtype, 8 * m->rows, (int)labels, m->nnz);
+    void *xh = nullptr, *yp = nullptr;
+    int rc = 1;
+    do {
+        if (!sub) break;
+        sub->owns_csr = true;
+        sub->stored = m->stored;
+        sub->d_row_ptr = vrp; sub->d_col = vcol; sub->d_val = vval;
+        sub->device_bytes = (int64_t)sizeof(int) * (8 * (int64_t)m->rows + 1) + m->stored * (4 + es);
+        vrp = nullptr; vcol = nullptr; vval = nullptr;                    // the handle frees them from here on
+        if (finish_from_device_csr(sub, 0, 0, m->dtype == SPMV_HIP_F64, st)) break;
+        sub->leave_empty_rows = true;                                     // the final sum skips empty virtual rows
+        SPMV_HIP_TRY(hipMalloc(&xh, (size_t)(labels * es)), break);
+        SPMV_HIP_TRY(hipMalloc(&yp, (size_t)(8 * (int64_t)m->rows * es)), break);
+        m->xcd_sub = sub; m->xcd_cpx = cpx;
+        m->d_hot_old = old_of_label; m->d_hot_x = xh; m->d_xcd_y = yp;
+        m->xcd_bytes = sub->device_bytes + labels * (4 + es) + 8 * (int64_t)m->rows * es;
+        m->device_bytes += m->xcd_bytes;
+        sub = nullptr; old_of_label = nullptr; xh = nullptr; yp = nullptr;
+        rc = 0;
+    } while (0);
+    if (sub) spmv_hip_free(sub);
+    void *scratch[] = {vrp, vcol, vval, old_of_label, xh, yp};
+    for (void *p : scratch)
+        if (p) (void)hipFree(p);
+    return rc;
 }
 
 int spmv_hip_set_option(spmv_hip_matrix *m, const char *name, int64_t value)
@@ -495,13 +540,15 @@ int spmv_hip_set_option(spmv_hip_matrix *m, const char *name, int64_t value)
     if (!strcmp(name, "variant")) { m->variant = (int)value; return 0; }
     if (!strcmp(name, "hot_columns")) {
         if (value == 0) { drop_hot_columns(m); return 0; }
-        if (m->d_hot_col) return 0;
+        if (value != 1 && value != 2) { set_error("hot_columns takes 0, 1 or 2"); return 1; }
+        if ((value == 1 && m->d_hot_col) || (value == 2 && m->xcd_sub)) return 0;
+        drop_hot_columns(m);
         if (m->format != SPMV_HIP_CSR_SCALAR && m->format != SPMV_HIP_CSR_VECTOR && m->format != SPMV_HIP_CSR_MERGE &&
             m->format != SPMV_HIP_CSR_BAL) {
             set_error("hot_columns needs a CSR-based format (scalar, vector, merge, balanced)");
             return 1;
         }
-        return build_hot_columns(m, nullptr);
+        return value == 1 ? build_hot_columns(m, nullptr) : build_xcd_split(m, nullptr);
     }
     set_error("unknown option '%s'", name);
     return 1;
@@ -527,8 +574,14 @@ static int analyze_impl(spmv_hip_matrix *m, int reps, float *best_ms_out)
     if (best_ms_out) *best_ms_out = 0;
     if (reps < 1) reps = 3;
     int cand[32];
-    const int n = variant_candidates(m, cand, 32);
+    int n = variant_candidates(m, cand, 32);
     if (m->rows == 0 || m->d_row_map) return 0;             // row-mapped handles write outside d_y
+    if (m->xcd_sub) {
+        // the product runs on the stacked handle: tune that one, then time the whole sequence once
+        if (analyze_impl(m->xcd_sub, reps, nullptr)) return 1;
+        n = 1;
+        cand[0] = m->format == SPMV_HIP_CSR_VECTOR ? m->lanes_per_row + 256 * m->variant : m->variant;
+    }
     if (n <= 1 && !best_ms_out) return 0;
     if (ensure_vectors(m)) return 1;
     const size_t es = dtype_size(m->dtype);
@@ -625,6 +678,20 @@ static spmv_hip_matrix *auto_from_device_csr(int rows, int columns, int64_t nnz,
         float ms = 0;
         if (build_hot_columns(best, st) == 0 && analyze_impl(best, reps, &ms) == 0 && ms < 0.95f * best_ms) {
             best_ms = ms;
+            // it pays: then the columns dealt over the XCDs may pay more (second copy of the matrix)
+            const int hot_variant = best->variant, hot_lanes = best->lanes_per_row;
+            drop_hot_columns(best);
+            if (build_xcd_split(best, st) == 0 && analyze_impl(best, reps, &ms) == 0 && ms < 0.95f * best_ms) {
+                best_ms = ms;
+            } else {
+                drop_hot_columns(best);
+                best->variant = hot_variant;
+                best->lanes_per_row = hot_lanes;
+                if (build_hot_columns(best, st)) {            // back to the plain handle
+                    best->variant = keep_variant;
+                    best->lanes_per_row = keep_lanes;
+                }
+            }
         } else {
             drop_hot_columns(best);
             best->variant = keep_variant;
@@ -681,7 +748,7 @@ int spmv_hip_get_info(const spmv_hip_matrix *m, spmv_hip_info *info)
     info->ntiles = m->ntiles; info->items_per_tile = m->items_per_tile;
     info->device_bytes = m->device_bytes;
     info->variant = m->variant;
-    info->hot_columns = m->d_hot_col != nullptr;
+    info->hot_columns = m->xcd_sub ? 2 : (m->d_hot_col != nullptr);
     return 0;
 }
 

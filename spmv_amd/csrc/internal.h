@@ -59,6 +59,7 @@ struct spmv_hip_matrix {
     int *d_nzr_id = nullptr;       // [nz_rows] original row index
     int *d_nzr_end = nullptr;      // [nz_rows] row end offsets (row_ptr[row+1])
     bool has_empty_rows = false;
+    bool leave_empty_rows = false;  // balanced CSR: y of empty rows is left alone (the caller skips them)
 
     // sliced formats (SELL-C-sigma, SELLP, ELL)
     int slice_height = 0, nslices = 0;
@@ -79,6 +80,13 @@ struct spmv_hip_matrix {
     int *d_hot_col = nullptr;
     int *d_hot_old = nullptr;
     void *d_hot_x = nullptr;
+    // "hot_columns" = 2: the columns dealt over the 8 XCDs.  xcd_sub is a balanced-CSR handle over the
+    // stacked matrix of 8*rows virtual rows and 8*xcd_cpx labels; d_hot_old / d_hot_x then have one
+    // entry per label, d_xcd_y holds the 8 partial results of every row
+    spmv_hip_matrix *xcd_sub = nullptr;
+    void *d_xcd_y = nullptr;
+    int xcd_cpx = 0;
+    int64_t xcd_bytes = 0;          // what the stacked handle and its vectors added to device_bytes
 
     // staging vectors for the host-pointer multiply and the bench loop
     void *d_x = nullptr, *d_y = nullptr;
@@ -103,6 +111,8 @@ int launch_scale(int n, const void *d_y, void *d_x, int dtype, const double *d_n
 // creator hands over dtype elements).
 int choose_lanes_per_row(int rows, int64_t stored);
 int build_hot_columns(spmv_hip_matrix *m, hipStream_t stream);                            // sort.hip
+int build_xcd_columns(const spmv_hip_matrix *m, bool val_is_f64, hipStream_t stream, int **vrow_ptr, int **vcol,
+                      void **vval, int **old_of_label, int *cpx);                         // sort.hip
 int device_exclusive_scan(const int *d_in, int *d_out, size_t n, hipStream_t stream);   // sort.hip (rocPRIM)
 int device_coo_to_csr(int rows, int columns, int64_t nnz, struct mtx *coo, bool values_f64, int **d_row_ptr,
                       int **d_col, void **d_val);                                         // sort.hip

@@ -977,7 +977,7 @@ template <typename T> static int launch_tiles(const spmv_hip_matrix *m, const T 
     const int *index = bal ? m->d_nzr_id : nullptr;
     const T *va = (const T *)m->d_val;
     T *vc = (T *)m->d_val_carry;
-    if (bal && m->has_empty_rows)
+    if (bal && m->has_empty_rows && !m->leave_empty_rows)
         SPMV_HIP_TRY(hipMemsetAsync(y, 0, (size_t)m->rows * sizeof(T), st), return 1);
     if (m->ntiles == 0) {
         if (!bal && m->rows > 0) SPMV_HIP_TRY(hipMemsetAsync(y, 0, (size_t)m->rows * sizeof(T), st), return 1);
@@ -1036,11 +1036,51 @@ __global__ __launch_bounds__(kBlock) void permute_x_kernel(int n, const int *__r
                                                            const T *__restrict__ x, T *__restrict__ xh)
 {
     int k = (int)(blockIdx.x * kBlock + threadIdx.x);
-    if (k < n) xh[k] = x[old_of_new[k]];
+    if (k >= n) return;
+    const int old = old_of_new[k];
+    xh[k] = old >= 0 ? x[old] : (T)0;             // labels without a column (dealing over the XCDs leaves up to 7)
+}
+
+// y[r] = the partial results of row r in group order; a group without entries in the row left
+// its slot unwritten and is skipped (its virtual row is empty)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sum_partials_kernel(int rows, const int *__restrict__ vrow_ptr,
+                                                              const T *__restrict__ part, T *__restrict__ y)
+{
+    int r = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (r >= rows) return;
+    T p[8];
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+        const size_t v = (size_t)g * rows + r;
+        p[g] = vrow_ptr[v + 1] > vrow_ptr[v] ? __builtin_nontemporal_load(part + v) : (T)0;
+    }
+    T s = p[0];
+#pragma unroll
+    for (int g = 1; g < 8; g++) s += p[g];
+    y[r] = s;
+}
+
+template <typename T>
+static int launch_mult_xcd(const spmv_hip_matrix *m, const T *x, T *y, hipStream_t st)
+{
+    const int labels = 8 * m->xcd_cpx;
+    hipLaunchKernelGGL((permute_x_kernel<T>), dim3(cdiv(labels, kBlock)), dim3(kBlock), 0, st, labels, m->d_hot_old, x,
+                       (T *)m->d_hot_x);
+    if (launch_mult(m->xcd_sub, m->d_hot_x, m->d_xcd_y, st)) return 1;
+    hipLaunchKernelGGL((sum_partials_kernel<T>), dim3(cdiv(m->rows, kBlock)), dim3(kBlock), 0, st, m->rows,
+                       m->xcd_sub->d_row_ptr, (const T *)m->d_xcd_y, y);
+    SPMV_HIP_TRY(hipGetLastError(), return 1);
+    return 0;
 }
 
 int launch_mult(const spmv_hip_matrix *m, const void *d_x, void *d_y, hipStream_t stream)
 {
+    if (m->xcd_sub && m->rows > 0) {
+        if (m->d_row_map) { set_error("hot_columns 2 does not combine with a row map"); return 1; }
+        return m->dtype == SPMV_HIP_F32 ? launch_mult_xcd<float>(m, (const float *)d_x, (float *)d_y, stream)
+                                        : launch_mult_xcd<double>(m, (const double *)d_x, (double *)d_y, stream);
+    }
     if (m->d_hot_col && m->rows > 0) {
         // permute x, then run the format's kernel on the relabeled column array
         const dim3 grid(cdiv(m->columns, kBlock)), block(kBlock);

@@ -277,6 +277,134 @@ int build_hot_columns(spmv_hip_matrix *m, hipStream_t st)
     return rc;
 }
 
+// ---- the same, with the columns dealt over the eight XCDs ----
+//
+// With one ranking for the whole chip every XCD's L2 ends up holding the same hottest columns.  Here
+// the ranking is dealt over eight groups in runs of 16 columns (group g owns the labels g*cpx ..
+// g*cpx+cpx-1, cpx = columns/8 rounded up to whole runs),
+// so each group owns a contiguous range of the permuted x with an equal share of the references and
+// its own hottest columns in front; the matrix is split by group into eight row-aligned pieces that
+// are stacked into one CSR of 8*rows "virtual" rows (piece g holds virtual rows g*rows..g*rows+rows-1).
+// The balanced kernel walks that CSR in storage order and its workgroup ids are mapped so that each
+// XCD takes one contiguous eighth of the tiles -- piece g, give or take a tile -- so the L2 of XCD g
+// only ever sees the columns of group g: eight times the cache for the hot columns.  A last pass
+// adds the eight partial results of every row in group order.
+
+constexpr int kXcds = 8;
+
+__global__ void xcd_label_kernel(int cols, int cpx, const int *__restrict__ old_of_rank,
+                                 int *__restrict__ label_of_old, int *__restrict__ old_of_label)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= cols) return;
+    // ranks are dealt in runs of 16 (one 128-byte line of doubles), so that columns which were
+    // neighbours in x and stayed neighbours in the ranking (equal counts) still share a line
+    const int run = k / 16, g = run % kXcds;
+    const int label = g * cpx + (run / kXcds) * 16 + k % 16;
+    const int old = old_of_rank[k];
+    label_of_old[old] = label;
+    old_of_label[label] = old;
+}
+
+// cnt[g*rows + r] = entries of row r whose column belongs to group g (thread per row; the eight
+// counters of a thread live in LDS, one bank per thread)
+__global__ __launch_bounds__(256) void xcd_count_kernel(int rows, int cpx, const int *__restrict__ row_ptr,
+                                                        const int *__restrict__ col,
+                                                        const int *__restrict__ label_of_old, int *__restrict__ cnt)
+{
+    __shared__ int c[kXcds][256];
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    for (int g = 0; g < kXcds; g++) c[g][threadIdx.x] = 0;
+    if (r < rows)
+        for (int e = row_ptr[r]; e < row_ptr[r + 1]; e++) c[label_of_old[col[e]] / cpx][threadIdx.x]++;
+    if (r < rows)
+        for (int g = 0; g < kXcds; g++) cnt[(size_t)g * rows + r] = c[g][threadIdx.x];
+}
+
+template <typename TIN, typename T>
+__global__ __launch_bounds__(256) void xcd_fill_kernel(int rows, int cpx, const int *__restrict__ row_ptr,
+                                                       const int *__restrict__ col, const TIN *__restrict__ val,
+                                                       const int *__restrict__ label_of_old,
+                                                       const int *__restrict__ vrow_ptr, int *__restrict__ vcol,
+                                                       T *__restrict__ vval)
+{
+    __shared__ int cursor[kXcds][256];
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    for (int g = 0; g < kXcds; g++) cursor[g][threadIdx.x] = vrow_ptr[(size_t)g * rows + r];
+    for (int e = row_ptr[r]; e < row_ptr[r + 1]; e++) {
+        const int label = label_of_old[col[e]];
+        const int at = cursor[label / cpx][threadIdx.x]++;
+        vcol[at] = label;
+        vval[at] = (T)val[e];
+    }
+}
+
+// Builds the stacked CSR for `m` (a CSR-based handle).  Outputs are hipMalloc'ed: the virtual row
+// pointers [8*rows+1], relabeled columns and values [stored], and the column of x behind every label
+// [8*cpx], -1 for the few unused labels.  0 on success.
+int build_xcd_columns(const spmv_hip_matrix *m, bool val_is_f64, hipStream_t st, int **out_vrp, int **out_vcol,
+                      void **out_vval, int **out_old_of_label, int *out_cpx)
+{
+    const int cols = m->columns, rows = m->rows;
+    const int64_t n = m->stored;
+    if (cols <= 0 || n <= 0 || rows <= 0) { set_error("hot_columns: empty matrix"); return 1; }
+    if ((int64_t)rows * kXcds > 0x7fffffffLL - 1) { set_error("hot_columns 2: %d rows x 8 exceed 32-bit row numbers", rows); return 1; }
+    const int cpx = (int)(((int64_t)cols + 16 * kXcds - 1) / (16 * kXcds)) * 16;
+    const size_t c = (size_t)cols, vrows = (size_t)rows * kXcds, labels = (size_t)cpx * kXcds;
+    unsigned *d_count[2] = {nullptr, nullptr};
+    int *d_id = nullptr, *d_rank_old = nullptr, *d_label_of_old = nullptr, *d_cnt = nullptr;
+    void *d_temp = nullptr;
+    int *vrp = nullptr, *vcol = nullptr, *old_of_label = nullptr;
+    void *vval = nullptr;
+    int rc = 1;
+    do {
+        SPMV_HIP_TRY(hipMalloc((void **)&d_count[0], c * sizeof(unsigned)), break);
+        SPMV_HIP_TRY(hipMalloc((void **)&d_count[1], c * sizeof(unsigned)), break);
+        SPMV_HIP_TRY(hipMalloc((void **)&d_id, c * sizeof(int)), break);
+        SPMV_HIP_TRY(hipMalloc((void **)&d_rank_old, c * sizeof(int)), break);
+        SPMV_HIP_TRY(hipMalloc((void **)&d_label_of_old, c * sizeof(int)), break);
+        SPMV_HIP_TRY(hipMalloc((void **)&old_of_label, labels * sizeof(int)), break);
+        SPMV_HIP_TRY(hipMalloc((void **)&d_cnt, (vrows + 1) * sizeof(int)), break);
+        SPMV_HIP_TRY(hipMalloc((void **)&vrp, (vrows + 1) * sizeof(int)), break);
+        SPMV_HIP_TRY(hipMalloc((void **)&vcol, (size_t)n * sizeof(int)), break);
+        SPMV_HIP_TRY(hipMalloc(&vval, (size_t)n * dtype_size(m->dtype)), break);
+        const dim3 block(256), gcol((unsigned)((c + 255) / 256)), gnz((unsigned)((n + 255) / 256)),
+            grow((unsigned)(((size_t)rows + 255) / 256));
+        SPMV_HIP_TRY(hipMemsetAsync(d_count[0], 0, c * sizeof(unsigned), st), break);
+        hipLaunchKernelGGL(column_count_kernel, gnz, block, 0, st, n, m->d_col, d_count[0]);
+        hipLaunchKernelGGL(iota_kernel, gcol, block, 0, st, cols, d_id);
+        size_t temp_bytes = 0;
+        SPMV_HIP_TRY(rocprim::radix_sort_pairs_desc(nullptr, temp_bytes, d_count[0], d_count[1], d_id, d_rank_old, c, 0, 32, st), break);
+        SPMV_HIP_TRY(hipMalloc(&d_temp, std::max<size_t>(temp_bytes, 16)), break);
+        SPMV_HIP_TRY(rocprim::radix_sort_pairs_desc(d_temp, temp_bytes, d_count[0], d_count[1], d_id, d_rank_old, c, 0, 32, st), break);
+        SPMV_HIP_TRY(hipMemsetAsync(old_of_label, 0xFF, labels * sizeof(int), st), break);
+        hipLaunchKernelGGL(xcd_label_kernel, gcol, block, 0, st, cols, cpx, d_rank_old, d_label_of_old, old_of_label);
+        hipLaunchKernelGGL(xcd_count_kernel, grow, block, 0, st, rows, cpx, m->d_row_ptr, m->d_col, d_label_of_old, d_cnt);
+        SPMV_HIP_TRY(hipMemsetAsync(d_cnt + vrows, 0, sizeof(int), st), break);
+        SPMV_HIP_TRY(hipGetLastError(), break);
+        if (device_exclusive_scan(d_cnt, vrp, vrows + 1, st)) break;
+        if (m->dtype == SPMV_HIP_F32 && val_is_f64)
+            hipLaunchKernelGGL((xcd_fill_kernel<double, float>), grow, block, 0, st, rows, cpx, m->d_row_ptr, m->d_col,
+                               (const double *)m->d_val, d_label_of_old, vrp, vcol, (float *)vval);
+        else if (m->dtype == SPMV_HIP_F32)
+            hipLaunchKernelGGL((xcd_fill_kernel<float, float>), grow, block, 0, st, rows, cpx, m->d_row_ptr, m->d_col,
+                               (const float *)m->d_val, d_label_of_old, vrp, vcol, (float *)vval);
+        else
+            hipLaunchKernelGGL((xcd_fill_kernel<double, double>), grow, block, 0, st, rows, cpx, m->d_row_ptr, m->d_col,
+                               (const double *)m->d_val, d_label_of_old, vrp, vcol, (double *)vval);
+        SPMV_HIP_TRY(hipGetLastError(), break);
+        SPMV_HIP_TRY(hipStreamSynchronize(st), break);
+        *out_vrp = vrp; *out_vcol = vcol; *out_vval = vval; *out_old_of_label = old_of_label; *out_cpx = cpx;
+        vrp = nullptr; vcol = nullptr; vval = nullptr; old_of_label = nullptr;
+        rc = 0;
+    } while (0);
+    void *scratch[] = {d_count[0], d_count[1], d_id, d_rank_old, d_label_of_old, d_cnt, d_temp, vrp, vcol, vval, old_of_label};
+    for (void *p : scratch)
+        if (p) (void)hipFree(p);
+    return rc;
+}
+
 } // namespace spmv
 
 // C-linkage hook for the host-only ingest file (mtxio.cpp is compiled without HIP headers)

@@ -123,6 +123,9 @@ def test_c3_rmat_scale26_kernels_agree():
             m.set_option("hot_columns", 1)
             assert torch.equal(_mult(m, x, rows), y_plain)
             del y_plain
+        if fmt == S.CSR_BAL:                                           # ... and dealt over the XCDs (537 M virtual rows)
+            m.set_option("hot_columns", 2)
+            assert _rel(_mult(m, x, rows), y_ref) <= 1e-13
         m.free()
         del y
         torch.cuda.empty_cache()
@@ -145,3 +148,25 @@ def test_c3_rmat_scale22_merge_and_balanced(orc):
         assert _rel(y, y_ref) <= 1e-13, (S.FORMAT_NAMES[fmt], p0)
         m.free()
     scalar.free()
+
+
+def test_rmat_scale24_auto_choice_is_right_whatever_it_relabels():
+    """create_auto on a graph matrix whose x (128 MB) is far beyond the L2: it may relabel the columns
+    by reference count or deal them over the XCDs; y must stay within the reduction tolerance of the
+    bit-exact lane-per-row kernel."""
+    rows, cols, rp, cj, va = G.rmat(24, 16, device=DEV)
+    nnz = int(rp[-1])
+    g = torch.Generator(device=DEV).manual_seed(23)
+    x = torch.rand(cols, dtype=torch.float64, device=DEV, generator=g) - 0.5
+    scalar = _dev_matrix(S.CSR_SCALAR, rows, cols, rp, cj, va)
+    y_ref = _mult(scalar, x, rows)
+    scalar.free()
+    st = torch.cuda.current_stream().cuda_stream
+    m = Matrix.auto_from_device_csr(rows, cols, nnz, rp.data_ptr(), cj.data_ptr(), va.data_ptr(), S.F64, 2, st,
+                                    keepalive=(rp, cj, va))
+    info = m.info
+    print("auto on rmat24:", S.FORMAT_NAMES[info.format], "variant", info.variant, "hot_columns", info.hot_columns)
+    assert _rel(_mult(m, x, rows), y_ref) <= 1e-13
+    assert _rel(_mult(m, 2.0 * x, rows), 2.0 * y_ref) <= 1e-13      # a second product: buffers are reused
+    assert info.hot_columns in (1, 2)                               # measured 1.6x: not a close call
+    m.free()

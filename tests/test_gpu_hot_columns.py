@@ -1,6 +1,8 @@
-"""Option "hot_columns": columns relabeled by reference count, x permuted per product.  The entries
-keep their places in the rows, so y must be bit-identical to the product of the same handle without
-the option (and thereby keeps its parity with the oracle's mult_csr_base, csr.c:4-13)."""
+"""Option "hot_columns": columns relabeled by reference count, x permuted per product.  With value 1
+the entries keep their places in the rows, so y must be bit-identical to the product of the same
+handle without the option (and thereby keeps its parity with the oracle's mult_csr_base,
+csr.c:4-13); with value 2 (columns dealt over the XCDs) every row is the sum of eight partial
+sums and parity is by the fp64 / fp32 tolerances of the reduction formats."""
 import numpy as np
 import pytest
 
@@ -63,6 +65,16 @@ def test_hot_columns_product_is_bit_identical(orc, name):
             m.analyze(1)                                   # variants are timed with the permutation in place
             assert orc.rel_l2(m.mult(x), plain) <= (1e-13 if dt == S.F64 else 2e-6)
             m.set_option("hot_columns", 1)                 # already on: nothing to do
+            # 2: the columns dealt over the XCDs -- eight partial sums per row, so parity by tolerance
+            m.set_option("hot_columns", 2)
+            assert m.info.hot_columns == 2
+            split = m.mult(x)
+            assert orc.rel_l2(split, plain) <= (1e-13 if dt == S.F64 else 2e-6), (name, fmt, dt)
+            if dt == S.F64:
+                mag = orc.mult_csr_base(rp, cj, np.abs(va), np.abs(x))
+                assert np.all(np.abs(split - want) <= 1e-12 * mag + 1e-300)
+            m.analyze(1)
+            assert orc.rel_l2(m.mult(x), plain) <= (1e-13 if dt == S.F64 else 2e-6)
             m.set_option("hot_columns", 0)
             assert m.info.hot_columns == 0 and m.info.device_bytes == bytes_plain
             m.free()

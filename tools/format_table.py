@@ -59,6 +59,8 @@ def main():
                 continue
             if name.endswith("+hot"):
                 m.set_option("hot_columns", 1)
+            if name.endswith("+xcd"):                       # columns dealt over the XCDs
+                m.set_option("hot_columns", 2)
             m.analyze(3)
             info = m.info
             variant = f"{info.lanes_per_row} lanes, {info.variant}" if fmt == S.CSR_VECTOR else str(info.variant)
