@@ -115,7 +115,7 @@ def run_matrix(name: str, scale: float, formats, dtypes, min_iters: int, min_sec
                 iters, seconds = timed_power_loop(m, x, y, dtype, min_iters, min_seconds, st)
                 variant = m.info.lanes_per_row * 256 + m.info.variant if fmt == S.CSR_VECTOR else m.info.variant
                 if mode == "auto":
-                    variant = f"{S.FORMAT_NAMES[fmt]}:{variant}"
+                    variant = f"{S.FORMAT_NAMES[fmt]}:{variant}" + ("", "+hot", "+xcd")[m.info.hot_columns]
                 m.free()
             except S.SpmvHipError as e:
                 lines.append(f"{mode};{name};{rows};{cols};{nnz};0;0;0;0;{'f64' if dtype == S.F64 else 'f32'};-1;0;nan;"
