@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--p0", default="0", help="comma list of p0 values (lanes / tile size / slice height)")
     ap.add_argument("--variants", default="0")
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--hot", type=int, default=0, help="option hot_columns of CSR-based handles (0, 1, 2)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     dtype = S.F64 if args.dtype == "f64" else S.F32
@@ -55,6 +56,8 @@ def main():
         pp0 = p0 or (64 if fmt in (S.SELL, S.SELL_DFC) else 0)
         m = Matrix.from_device_csr(fmt, rows, cols, nnz, rp.data_ptr(), cj.data_ptr(), va.data_ptr(), dtype, pp0,
                                    args.sigma if fmt in (S.SELL, S.SELL_DFC) else 0, st)
+        if args.hot:
+            m.set_option("hot_columns", args.hot)
         for var in [v if v == "auto" else int(v) for v in args.variants.split(",")]:
             if var == "auto":
                 m.analyze(3)
