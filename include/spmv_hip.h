@@ -76,6 +76,8 @@ typedef struct spmv_hip_info {
     int64_t device_bytes; /* HBM held by the handle                                   */
     int     variant;      /* kernel variant in use (spmv_hip_set_option / spmv_hip_analyze) */
     int     hot_columns;  /* option "hot_columns": 0 off, 1 columns relabeled by reference count, 2 dealt over the XCDs */
+    int64_t diag_columns; /* sliced formats of height 64: slice columns (64 entries each) whose entries all sit at
+                             one distance from the diagonal; the variants >= 16 do not read their indices */
 } spmv_hip_info;
 
 /* Selects the device for subsequent creators on this thread (hipSetDevice). */

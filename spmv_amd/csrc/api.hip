@@ -426,7 +426,7 @@ int spmv_hip_free(spmv_hip_matrix *m)
     release_csr(m);
     void *ptrs[] = {m->d_tile_coord, m->d_row_carry, m->d_val_carry, m->d_nzr_id, m->d_nzr_end, m->d_slice_ptr,
                     m->d_row_order, m->d_slice_ident, m->d_scol, m->d_sval, m->d_sorted_len, m->d_vop_ptr, m->d_vop_len,
-                    m->d_x, m->d_y, m->d_norm, m->d_hot_col, m->d_hot_old, m->d_hot_x, m->d_xcd_y};
+                    m->d_x, m->d_y, m->d_norm, m->d_hot_col, m->d_hot_old, m->d_hot_x, m->d_xcd_y, m->d_sdiag};
     if (m->xcd_sub) spmv_hip_free(m->xcd_sub);
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -749,6 +749,7 @@ int spmv_hip_get_info(const spmv_hip_matrix *m, spmv_hip_info *info)
     info->device_bytes = m->device_bytes;
     info->variant = m->variant;
     info->hot_columns = m->xcd_sub ? 2 : (m->d_hot_col != nullptr);
+    info->diag_columns = m->diag_columns;
     return 0;
 }
 

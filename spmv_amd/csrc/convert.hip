@@ -5,6 +5,8 @@
 
 #include "internal.h"
 
+#include <climits>
+
 #include <algorithm>
 #include <vector>
 
@@ -469,6 +471,41 @@ int build_sell_dfc(spmv_hip_matrix *m, const int *d_row_ptr, const int *d_col, c
     return rc;
 }
 
+// Column j of a slice is "diagonal" when all its real entries sit at the same distance from their
+// own row: col = row + d (the rows of one grid line of a stencil, a band, a block diagonal).  Such a
+// column is described by the single number d, so a kernel that knows it need not read the 64 column
+// indices.  diag[first column of slice s + j] = d, or INT_MIN when the column is not diagonal;
+// *ndiag counts the diagonal ones.  One wave per slice; padding lanes (j >= length of their row) are
+// free.
+__global__ __launch_bounds__(kWave) void slice_diag_kernel(int rows, int nslices, const int *__restrict__ row_ptr,
+                                                           const int *__restrict__ row_order,
+                                                           const int64_t *__restrict__ slice_ptr,
+                                                           const int *__restrict__ scol, int *__restrict__ diag,
+                                                           unsigned long long *__restrict__ ndiag)
+{
+    const int s = blockIdx.x, lane = threadIdx.x;
+    if (s >= nslices) return;
+    const int r = s * kWave + lane;
+    const int row = r < rows ? (row_order ? row_order[r] : r) : 0;
+    const int len = r < rows ? row_ptr[row + 1] - row_ptr[row] : 0;
+    const int64_t base = slice_ptr[s];
+    const int width = (int)((slice_ptr[s + 1] - base) >> 6);
+    int found = 0;
+    for (int j = 0; j < width; j++) {
+        const bool real = j < len;
+        const int d = real ? scol[base + (int64_t)j * kWave + lane] - row : 0;
+        const unsigned long long mask = __ballot(real);
+        int out = 0;                                           // a column of padding only: any distance will do
+        if (mask) {
+            const int d0 = __builtin_amdgcn_readlane(d, __builtin_ctzll(mask));
+            out = __ballot(real && d != d0) ? INT_MIN : d0;
+        }
+        if (lane == 0) diag[(base >> 6) + j] = out;
+        found += out != INT_MIN;
+    }
+    if (lane == 0 && found) atomicAdd(ndiag, (unsigned long long)found);
+}
+
 int build_sliced(spmv_hip_matrix *m, const int *d_row_ptr, const int *d_col, const void *d_val,
                  bool val_is_f64, bool sorted, hipStream_t st)
 {
@@ -554,6 +591,23 @@ int build_sliced(spmv_hip_matrix *m, const int *d_row_ptr, const int *d_col, con
                                    (const float *)d_val, m->d_row_order, m->d_slice_ptr, m->d_scol, (float *)m->d_sval);
             else { set_error("sliced: float CSR values cannot build a double matrix"); break; }
             SPMV_HIP_TRY(hipGetLastError(), break);
+        }
+        if (total > 0 && H == kWave) {
+            // one number per slice column: the distance of its entries from the diagonal, where they share one
+            unsigned long long *d_count = nullptr, count = 0;
+            if (dev_alloc(m, &m->d_sdiag, (size_t)(total / kWave))) break;
+            if (dev_alloc<unsigned long long>(nullptr, &d_count, 1)) break;
+            bool ok = hipMemsetAsync(d_count, 0, sizeof count, st) == hipSuccess;
+            if (ok) {
+                hipLaunchKernelGGL(slice_diag_kernel, dim3((unsigned)m->nslices), dim3(kWave), 0, st, rows, m->nslices,
+                                   d_row_ptr, m->d_row_order, m->d_slice_ptr, m->d_scol, m->d_sdiag, d_count);
+                ok = hipGetLastError() == hipSuccess &&
+                     hipMemcpyAsync(&count, d_count, sizeof count, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                     hipStreamSynchronize(st) == hipSuccess;
+            }
+            (void)hipFree(d_count);
+            if (!ok) { set_error("sliced: scanning the slice columns for diagonals failed"); break; }
+            m->diag_columns = (int64_t)count;
         }
         SPMV_HIP_TRY(hipStreamSynchronize(st), break);
         rc = 0;

@@ -69,6 +69,9 @@ struct spmv_hip_matrix {
     unsigned char *d_slice_ident = nullptr; // nslices (SELL only): 1 = the slice's rows kept their places
     int *d_scol = nullptr;          // stored
     void *d_sval = nullptr;         // stored (dtype)
+    int *d_sdiag = nullptr;         // stored/64 (height 64 only): per slice column, col - row where all its entries
+                                    // share it, INT_MIN otherwise
+    int64_t diag_columns = 0;       // how many slice columns have one
     // SELL without padding: length of the row at every sorted position, columns per slice, active lanes
     int *d_sorted_len = nullptr;    // rows
     int64_t *d_vop_ptr = nullptr;   // nslices+1

@@ -21,6 +21,8 @@
 #include "device_utils.h"
 
 #include <algorithm>
+#include <type_traits>
+#include <climits>
 
 namespace spmv {
 
@@ -395,6 +397,64 @@ __global__ __launch_bounds__(kBlock) void sliced64_wide_kernel(int rows, int nsl
     }
     int r = s * kWave + lane;
     if (r < rows) y[PERM && !slice_ident[s] ? row_order[r] : r] = mine;
+}
+
+// sliced64_diag_kernel: the exact-order kernel for slices whose columns run along diagonals.  The
+// build pass left one number per slice column (sdiag): the distance col - row when all real entries
+// of the column share it, INT_MIN otherwise.  For a diagonal column the 64 column indices are not
+// read: lane k gathers x[row_k + d] (padding lanes carry value 0 and clamp the address into x).  A
+// 27-point stencil, a band or a block-diagonal matrix then streams 8 (fp64) instead of 12 bytes per
+// entry.  The descriptor is wave-uniform, so the choice is a scalar branch.  One fma per column in
+// ascending column order: bit-identical to sliced64_kernel and mult_csr_base (csr.c:4-13) for
+// finite x.
+template <typename T, bool PERM, int U, bool NT>
+__global__ __launch_bounds__(kBlock) void sliced64_diag_kernel(int rows, int cols, int nslices,
+                                                               const int64_t *__restrict__ slice_ptr,
+                                                               const int *__restrict__ row_order,
+                                                               const unsigned char *__restrict__ slice_ident,
+                                                               const int *__restrict__ sdiag,
+                                                               const int *__restrict__ scol,
+                                                               const T *__restrict__ sval,
+                                                               const T *__restrict__ x, T *__restrict__ y)
+{
+    unsigned b = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    int s = __builtin_amdgcn_readfirstlane((int)(b * (kBlock / kWave) + threadIdx.x / kWave));
+    if (s >= nslices) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int r = s * kWave + lane;
+    const int row = r < rows ? (PERM && !slice_ident[s] ? row_order[r] : r) : 0;
+    const int64_t base = slice_ptr[s];
+    const int width = (int)((slice_ptr[s + 1] - base) >> 6);
+    const T *v = sval + base + lane;
+    const int *c = scol + base + lane;
+    const int *dg = sdiag + (base >> 6);
+    const int last = cols - 1;
+    T acc = 0;
+    int j = 0;
+    // B columns at once: value loads, descriptors / index loads, gathers, then the fmas in column order
+    auto batch = [&](auto bsize) {
+        constexpr int B = decltype(bsize)::value;
+        int cc[B];
+        T vv[B], xx[B];
+#pragma unroll
+        for (int u = 0; u < B; u++) vv[u] = NT ? __builtin_nontemporal_load(v + (int64_t)(j + u) * kWave) : v[(int64_t)(j + u) * kWave];
+#pragma unroll
+        for (int u = 0; u < B; u++) {
+            const int d = __builtin_amdgcn_readfirstlane(dg[j + u]);
+            if (d != INT_MIN) cc[u] = min(max(row + d, 0), last);
+            else cc[u] = NT ? __builtin_nontemporal_load(c + (int64_t)(j + u) * kWave) : c[(int64_t)(j + u) * kWave];
+        }
+#pragma unroll
+        for (int u = 0; u < B; u++) xx[u] = x[cc[u]];
+#pragma unroll
+        for (int u = 0; u < B; u++) acc = fma_t(xx[u], vv[u], acc);
+        j += B;
+    };
+    while (j + U <= width) batch(std::integral_constant<int, U>());
+    if (U > 4)
+        while (j + 4 <= width) batch(std::integral_constant<int, 4>());
+    while (j < width) batch(std::integral_constant<int, 1>());
+    if (r < rows) y[row] = acc;
 }
 
 // ----------------------------------------- SELL-C-sigma without padding (DFC) --
@@ -842,6 +902,10 @@ int variant_candidates(const spmv_hip_matrix *m, int *out, int max_out)
     } else if (sliced64) {
         for (int v : kSlicedVariants)
             if (n < max_out) out[n++] = v;
+        // the kernels that skip the indices of diagonal columns, when at least half the columns are
+        if (m->d_sdiag && m->diag_columns * 2 * kWave >= m->stored)
+            for (int v : {16, 17, 18, 19, 20, 21, 22, 23})
+                if (n < max_out) out[n++] = v;
     } else if (m->format == SPMV_HIP_CSR_VECTOR) {
         // vector CSR: candidates are (lanes per row) + 256 * (variant = rows side by side, see launch_csr_vector)
         for (int g = 2; g <= 64; g *= 2)
@@ -884,6 +948,22 @@ static int launch_sliced64(const spmv_hip_matrix *m, const T *x, T *y, hipStream
     case 10: SPMV_WIDE(4, true); break;
     case 11: SPMV_WIDE(7, true); break;
     case 12: SPMV_WIDE(14, true); break;
+#define SPMV_DIAG(V, U, NT)                                                                                \
+    case V:                                                                                                \
+        if (!m->d_sdiag && m->stored > 0) { set_error("sliced format: variant %d needs the diagonal descriptors", V); return 1; } \
+        hipLaunchKernelGGL((sliced64_diag_kernel<T, PERM, U, NT>), grid, block, 0, st, m->rows, m->columns, \
+                           m->nslices, m->d_slice_ptr, m->d_row_order, m->d_slice_ident, m->d_sdiag, m->d_scol, sv, x, y); \
+        break;
+        // 16..19: columns along diagonals are not read (8, 9, 27, 16 columns per batch); 20..23: non-temporal loads
+        SPMV_DIAG(16, 8, false)
+        SPMV_DIAG(17, 9, false)
+        SPMV_DIAG(18, 27, false)
+        SPMV_DIAG(19, 16, false)
+        SPMV_DIAG(20, 8, true)
+        SPMV_DIAG(21, 9, true)
+        SPMV_DIAG(22, 27, true)
+        SPMV_DIAG(23, 16, true)
+#undef SPMV_DIAG
     default: set_error("sliced format: unknown kernel variant %d", m->variant); return 1;
     }
 #undef SPMV_WIDE

@@ -219,6 +219,8 @@ def test_sell_window_with_a_very_long_row(orc):
 
 
 SLICED_VARIANTS = [1, 2, 3, 4, 9, 10, 11, 12]
+# lane per row, one fma per column in order, column indices of diagonal slice columns not read
+DIAG_VARIANTS = [16, 17, 18, 19, 20, 21, 22, 23]
 
 
 @pytest.mark.parametrize("fmt", ["sell", "sellp"])
@@ -238,11 +240,43 @@ def test_sliced_wide_variants_and_analyze(orc, g, fmt):
             assert not np.isnan(y).any()
             assert rel(orc, y, ref) <= tol, (v, dtype)
         chosen = m.analyze(2)
-        assert chosen in [0] + SLICED_VARIANTS
+        assert chosen in [0] + SLICED_VARIANTS + DIAG_VARIANTS
         assert rel(orc, m.mult(xin), ref) <= tol
         with pytest.raises(S.SpmvHipError, match="variant"):
             m.set_option("variant", 99)
             m.mult(xin)
+        m.free()
+
+
+@pytest.mark.parametrize("fmt", ["sell", "sell64", "sellp", "ell"])
+def test_sliced_diagonal_variants_bitwise(orc, g, fmt):
+    """The kernels that replace the indices of a diagonal slice column by one distance keep the
+    lane-per-row order: bit-identical to the reference's y_csr_base, whatever share of the columns
+    is diagonal (none on the random fixtures, nearly all on the grids)."""
+    rows, cols = int(g["rows"]), int(g["cols"])
+    csr = (g["csr1_row_ptr"], g["csr1_col"], g["csr1_val"])
+    want32 = orc.mult_csr_base_f32(csr[0], csr[1], csr[2].astype(np.float32), g["x"].astype(np.float32))
+    for dtype in (S.F64, S.F32):
+        if fmt == "sell":
+            m = Matrix.sell(rows, cols, *csr, dtype, 64, 1024)
+        elif fmt == "sell64":
+            m = Matrix.sell(rows, cols, *csr, dtype, 64, 64)
+        elif fmt == "sellp":
+            m = Matrix.sellp(rows, cols, *csr, dtype, 64)
+        else:
+            m = Matrix.ell(rows, cols, coo_of(g, "in"), dtype, 64)
+        info = m.info
+        assert 0 <= info.diag_columns <= info.stored // 64
+        if g["name"] in ("band_500_5", "diag_64") and fmt != "sell":      # small grids break off at every grid line
+            assert info.diag_columns * 64 >= 0.5 * info.stored, (g["name"], info.diag_columns, info.stored)
+        xin = g["x"].astype(np.float32).astype(np.float64) if dtype == S.F32 else g["x"]
+        for v in DIAG_VARIANTS:
+            m.set_option("variant", v)
+            y = m.mult(xin)
+            if dtype == S.F64:
+                assert bits_equal(y, g["y_csr_base"]), (fmt, v)
+            else:
+                assert bits_equal(y.astype(np.float32), want32), (fmt, v)
         m.free()
 
 
