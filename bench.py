@@ -268,7 +268,7 @@ def main():
         achieved = b_alg / (mean_kernel_ms * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        key = f"{args.format}/{args.matrix}/{n}/{args.dtype}/gpus{world}"
+        key = f"{args.format}/{args.matrix}/{n}/{args.dtype}/gpus{world}/variant{variant}"   # PMC figure of that kernel
         if os.path.exists(tfile):
             traffic = json.load(open(tfile)).get(key)
         out = {
