@@ -78,6 +78,8 @@ typedef struct spmv_hip_info {
     int     hot_columns;  /* option "hot_columns": 0 off, 1 columns relabeled by reference count, 2 dealt over the XCDs */
     int64_t diag_columns; /* sliced formats of height 64: slice columns (64 entries each) whose entries all sit at
                              one distance from the diagonal; the variants >= 16 do not read their indices */
+    int     pattern_blocks; /* CSR_SCALAR: blocks of 64 rows that repeat one pattern of distances from the
+                             diagonal; the variants >= 16 read one row's indices for each */
 } spmv_hip_info;
 
 /* Selects the device for subsequent creators on this thread (hipSetDevice). */

@@ -130,7 +130,7 @@ static int finish_from_device_csr(spmv_hip_matrix *m, int64_t p0, int64_t p1, bo
         return 1;
     }
     switch (m->format) {
-    case SPMV_HIP_CSR_SCALAR: m->lanes_per_row = 1; return 0;
+    case SPMV_HIP_CSR_SCALAR: m->lanes_per_row = 1; return build_block_patterns(m, st);
     case SPMV_HIP_CSR_VECTOR: {
         int g = p0 ? (int)p0 : choose_lanes_per_row(m->rows, m->stored);
         if (g < 2 || g > 64 || (g & (g - 1))) { set_error("lanes_per_row %d must be a power of two in 2..64", g); return 1; }
@@ -426,7 +426,7 @@ int spmv_hip_free(spmv_hip_matrix *m)
     release_csr(m);
     void *ptrs[] = {m->d_tile_coord, m->d_row_carry, m->d_val_carry, m->d_nzr_id, m->d_nzr_end, m->d_slice_ptr,
                     m->d_row_order, m->d_slice_ident, m->d_scol, m->d_sval, m->d_sorted_len, m->d_vop_ptr, m->d_vop_len,
-                    m->d_x, m->d_y, m->d_norm, m->d_hot_col, m->d_hot_old, m->d_hot_x, m->d_xcd_y, m->d_sdiag};
+                    m->d_x, m->d_y, m->d_norm, m->d_hot_col, m->d_hot_old, m->d_hot_x, m->d_xcd_y, m->d_sdiag, m->d_block_pat};
     if (m->xcd_sub) spmv_hip_free(m->xcd_sub);
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -750,6 +750,7 @@ int spmv_hip_get_info(const spmv_hip_matrix *m, spmv_hip_info *info)
     info->variant = m->variant;
     info->hot_columns = m->xcd_sub ? 2 : (m->d_hot_col != nullptr);
     info->diag_columns = m->diag_columns;
+    info->pattern_blocks = m->pat_blocks;
     return 0;
 }
 

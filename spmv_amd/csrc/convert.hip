@@ -471,6 +471,56 @@ int build_sell_dfc(spmv_hip_matrix *m, const int *d_row_ptr, const int *d_col, c
     return rc;
 }
 
+// pattern_len[b] = L when the 64 rows of block b all have L entries (1 <= L <= 32) and entry k of
+// every row sits at the same distance from the diagonal; 0 otherwise (and for the last, partial
+// block).  One wave per block, lane = row.
+__global__ __launch_bounds__(kWave) void csr_block_pattern_kernel(int rows, int columns, const int *__restrict__ row_ptr,
+                                                                  const int *__restrict__ col,
+                                                                  unsigned char *__restrict__ pattern_len,
+                                                                  int *__restrict__ npat)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int row = b * kWave + lane;
+    int out = 0;
+    if (b * kWave + kWave <= rows) {                      // wave-uniform
+        const int beg = row_ptr[row], len = row_ptr[row + 1] - beg;
+        const int L = __builtin_amdgcn_readfirstlane(len);
+        bool same = len == L;
+        if (!__ballot(!same) && L >= 1 && L <= 32) {
+            for (int k = 0; k < L; k++) {
+                const int d = col[beg + k] - row;
+                same = same && d == __builtin_amdgcn_readfirstlane(d);
+            }
+            if (!__ballot(!same)) out = L;
+        }
+    }
+    if (lane == 0) {
+        pattern_len[b] = (unsigned char)out;
+        if (out) atomicAdd(npat, 1);
+    }
+}
+
+int build_block_patterns(spmv_hip_matrix *m, hipStream_t st)
+{
+    const int nblocks = (m->rows + kWave - 1) / kWave;
+    if (nblocks == 0 || m->stored == 0) return 0;
+    int *d_count = nullptr, count = 0;
+    if (dev_alloc(m, &m->d_block_pat, (size_t)nblocks)) return 1;
+    if (dev_alloc<int>(nullptr, &d_count, 1)) return 1;
+    bool ok = hipMemsetAsync(d_count, 0, sizeof(int), st) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(csr_block_pattern_kernel, dim3((unsigned)nblocks), dim3(kWave), 0, st, m->rows, m->columns,
+                           m->d_row_ptr, m->d_col, m->d_block_pat, d_count);
+        ok = hipGetLastError() == hipSuccess &&
+             hipMemcpyAsync(&count, d_count, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess &&
+             hipStreamSynchronize(st) == hipSuccess;
+    }
+    (void)hipFree(d_count);
+    if (!ok) { set_error("csr: scanning the row blocks for patterns failed"); return 1; }
+    m->pat_blocks = count;
+    return 0;
+}
+
 // Column j of a slice is "diagonal" when all its real entries sit at the same distance from their
 // own row: col = row + d (the rows of one grid line of a stencil, a band, a block diagonal).  Such a
 // column is described by the single number d, so a kernel that knows it need not read the 64 column

@@ -46,6 +46,9 @@ struct spmv_hip_matrix {
     void *d_val = nullptr;
     int lanes_per_row = 0;
     const int *d_row_map = nullptr; // CSR_SCALAR / CSR_VECTOR: matrix row k writes y[row_map[k]] (caller's array)
+    unsigned char *d_block_pat = nullptr; // CSR_SCALAR: per block of 64 rows, the common row length when all its
+                                          // rows repeat one pattern of distances from the diagonal, else 0
+    int pat_blocks = 0;            // how many blocks do
     int variant = 0;               // kernel variant inside the format (spmv_hip_set_option "variant")
     double max_padding = 0;        // > 0: building a sliced layout fails when stored > max_padding * nnz
 
@@ -119,6 +122,7 @@ int build_xcd_columns(const spmv_hip_matrix *m, bool val_is_f64, hipStream_t str
 int device_exclusive_scan(const int *d_in, int *d_out, size_t n, hipStream_t stream);   // sort.hip (rocPRIM)
 int device_coo_to_csr(int rows, int columns, int64_t nnz, struct mtx *coo, bool values_f64, int **d_row_ptr,
                       int **d_col, void **d_val);                                         // sort.hip
+int build_block_patterns(spmv_hip_matrix *m, hipStream_t stream);
 int build_merge_tiles(spmv_hip_matrix *m, hipStream_t stream);
 int build_bal_tiles(spmv_hip_matrix *m, hipStream_t stream);
 int build_sliced(spmv_hip_matrix *m, const int *d_row_ptr, const int *d_col, const void *d_val,

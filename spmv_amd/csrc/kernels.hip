@@ -150,6 +150,91 @@ __global__ __launch_bounds__(kWave) void csr_rows_lds_kernel(int rows, const int
     if (row < rows) y[row_map ? row_map[row] : row] = acc;
 }
 
+// The same kernel for matrices whose rows repeat one pattern.  A block of 64 consecutive rows is
+// "patterned" when all its rows have the same length L <= 32 and entry k of every row sits at the
+// same distance from the diagonal (grids away from their boundaries, bands, block diagonals); the
+// build pass leaves L (0 = not patterned) in one byte per block.  For such a block only the first
+// row's L column indices are read: entry e of the block's run belongs to row e / L and column
+// row + distance[e % L].  The value stream, the gathers, the LDS staging and the in-order row sums
+// are those of csr_rows_lds_kernel, so y stays bit-identical to mult_csr_base (csr.c:4-13); the
+// stream shrinks from V + 4 to V bytes per entry.
+template <typename T, int IPL, bool NT>
+__global__ __launch_bounds__(kWave) void csr_rows_lds_pat_kernel(int rows, const int *__restrict__ row_ptr,
+                                                                 const int *__restrict__ col,
+                                                                 const T *__restrict__ val,
+                                                                 const unsigned char *__restrict__ pattern_len,
+                                                                 const int *__restrict__ row_map,
+                                                                 const T *__restrict__ x, T *__restrict__ y)
+{
+    constexpr int kCap = kWave * IPL;
+    __shared__ xv_pair<T> stage[kCap];
+    __shared__ int dist[32];
+    const int blk = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int lane = threadIdx.x;
+    const int row0 = blk * kWave;
+    const int row = row0 + lane;
+    const int last = min(row0 + kWave, rows);
+    const int rs = row_ptr[min(row, rows)];
+    const int re = row < rows ? row_ptr[row + 1] : rs;
+    const int run_begin = __builtin_amdgcn_readfirstlane(rs);
+    const int run_end = row_ptr[last];
+    const int L = pattern_len[blk];                       // wave-uniform
+    const float inv_len = L ? 1.0f / (float)L : 0.0f;
+    if (L) {
+        if (lane < L) dist[lane] = col[run_begin + lane] - row0;
+        __syncthreads();
+    }
+    T acc = 0;
+    auto load_chunk = [&](int e0, int (&cc)[IPL], T (&vv)[IPL]) {
+#pragma unroll
+        for (int i = 0; i < IPL; i++) {
+            const int at = min(max(e0 + lane + i * kWave, run_begin), run_end - 1);
+            if (L) {
+                const int rel = at - run_begin;
+                const int r = (int)(((float)rel + 0.5f) * inv_len);      // rel / L, exact for rel < 2048
+                cc[i] = row0 + r + dist[rel - r * L];
+            } else {
+                cc[i] = NT ? __builtin_nontemporal_load(col + at) : col[at];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < IPL; i++) {
+            const T *p = val + min(max(e0 + lane + i * kWave, run_begin), run_end - 1);
+            vv[i] = NT ? __builtin_nontemporal_load(p) : *p;
+        }
+    };
+    int cc[IPL];
+    T vv[IPL];
+    const int first = run_begin & ~31;
+    if (run_begin < run_end) load_chunk(first, cc, vv);
+    for (int e0 = first; e0 < run_end; e0 += kCap) {
+        const int n = min(kCap, run_end - e0);
+        T xx[IPL];
+        int cnext[IPL];
+        T vnext[IPL];
+#pragma unroll
+        for (int i = 0; i < IPL; i++) xx[i] = x[cc[i]];
+        if (e0 + kCap < run_end) load_chunk(e0 + kCap, cnext, vnext);
+#pragma unroll
+        for (int i = 0; i < IPL; i++) stage[lane + i * kWave] = xv_pair<T>{xx[i], vv[i]};
+#pragma unroll
+        for (int i = 0; i < IPL; i++) { cc[i] = cnext[i]; vv[i] = vnext[i]; }
+        __syncthreads();
+        int k = max(rs, e0) - e0;
+        const int kend = min(re, e0 + n) - e0;
+        for (; k + 4 <= kend; k += 4) {
+            xv_pair<T> p[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) p[u] = stage[k + u];
+#pragma unroll
+            for (int u = 0; u < 4; u++) acc = fma_t(p[u].x, p[u].v, acc);
+        }
+        for (; k < kend; k++) acc = fma_t(stage[k].x, stage[k].v, acc);
+        __syncthreads();
+    }
+    if (row < rows) y[row_map ? row_map[row] : row] = acc;
+}
+
 // --------------------------------------------------------- CSR, G lanes/row --
 
 // Each group of G lanes owns R consecutive rows and walks them side by side, so
@@ -918,6 +1003,10 @@ int variant_candidates(const spmv_hip_matrix *m, int *out, int max_out)
         // LDS chunk sizes of the staged lane-per-row kernel (all give the same bits)
         for (int v : {0, 2, 3, 4, 8, 10, 11, 12})
             if (n < max_out) out[n++] = v;
+        // the kernels that read one row's indices per patterned block, when at least half the blocks are
+        if (m->d_block_pat && !m->d_hot_col && m->pat_blocks * 2 * kWave >= m->rows)
+            for (int v : {16, 17, 18, 20, 21, 22})
+                if (n < max_out) out[n++] = v;
     } else if (m->format == SPMV_HIP_CSR_MERGE || m->format == SPMV_HIP_CSR_BAL) {
         for (int v : {0, 1})
             if (n < max_out) out[n++] = v;
@@ -1033,7 +1122,8 @@ template <typename T> static int launch_csr_scalar(const spmv_hip_matrix *m, con
                            va, m->d_row_map, x, y);                                                      \
         break;
 #define SPMV_ROWS_CASE(V, I) SPMV_ROWS_ONE(V, I, false) SPMV_ROWS_ONE(V + 8, I, true)
-    switch (m->variant) {
+    // a matrix without entries has no patterns to read: any chunked kernel writes its zeros
+    switch (m->variant >= 16 && m->variant <= 22 && !m->d_block_pat && m->stored == 0 ? 0 : m->variant) {
         SPMV_ROWS_CASE(0, 8)
         SPMV_ROWS_CASE(2, 16)
         SPMV_ROWS_CASE(3, 4)
@@ -1042,6 +1132,20 @@ template <typename T> static int launch_csr_scalar(const spmv_hip_matrix *m, con
         hipLaunchKernelGGL((csr_scalar_kernel<T>), dim3(cdiv(m->rows, kBlock)), dim3(kBlock), 0, st, m->rows,
                            m->d_row_ptr, m->d_col, va, m->d_row_map, x, y);
         break;
+#define SPMV_ROWS_PAT(V, I, NT)                                                                          \
+    case V:                                                                                              \
+        if (!m->d_block_pat) { set_error("scalar CSR: variant %d needs the block patterns", V); return 1; } \
+        hipLaunchKernelGGL((csr_rows_lds_pat_kernel<T, I, NT>), grid, block, 0, st, m->rows, m->d_row_ptr, m->d_col, \
+                           va, m->d_block_pat, m->d_row_map, x, y);                                      \
+        break;
+        // 16..18: patterned row blocks read one row's column indices (512, 1024, 256 entries per chunk); 20..22: non-temporal
+        SPMV_ROWS_PAT(16, 8, false)
+        SPMV_ROWS_PAT(17, 16, false)
+        SPMV_ROWS_PAT(18, 4, false)
+        SPMV_ROWS_PAT(20, 8, true)
+        SPMV_ROWS_PAT(21, 16, true)
+        SPMV_ROWS_PAT(22, 4, true)
+#undef SPMV_ROWS_PAT
     default: set_error("scalar CSR: unknown kernel variant %d", m->variant); return 1;
     }
 #undef SPMV_ROWS_CASE
@@ -1173,6 +1277,12 @@ int launch_mult(const spmv_hip_matrix *m, const void *d_x, void *d_y, hipStream_
         spmv_hip_matrix view = *m;
         view.d_col = m->d_hot_col;
         view.d_hot_col = nullptr;
+        // the block patterns describe the caller's column numbers, not the relabeled ones
+        view.d_block_pat = nullptr;
+        if (view.format == SPMV_HIP_CSR_SCALAR && view.variant >= 16) {
+            const int plain[] = {0, 2, 3, 3, 8, 10, 11, 11};              // same chunk size (or the next), every index read
+            view.variant = plain[(view.variant - 16) & 7];
+        }
         return launch_mult(&view, m->d_hot_x, d_y, stream);
     }
     if (m->dtype == SPMV_HIP_F32) return launch_mult_t<float>(m, (const float *)d_x, (float *)d_y, stream);

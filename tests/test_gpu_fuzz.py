@@ -79,6 +79,10 @@ def test_every_format_on_random_shapes(orc, seed):
             assert orc.rel_l2(y, want) <= 1e-13, (name, seed)
         m.analyze(1)                                 # whatever variant wins must still be right
         assert orc.rel_l2(m.mult(x), want) <= 1e-13, (name, seed, m.info.variant)
+        if name == "csr_scalar":                                   # patterned-block kernels
+            for v in (16, 22):
+                m.set_option("variant", v)
+                assert bits_equal(m.mult(x), want), (name, seed, v)
         if name in ("sell_64", "sell_1024", "sellp", "ell"):      # diagonal-column kernels (clamped padding lanes)
             for v in (16, 22):
                 m.set_option("variant", v)

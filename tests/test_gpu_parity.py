@@ -63,6 +63,8 @@ def test_csr_scalar_bitwise(g):
 
 # LDS-staged chunk sizes 0, 2, 3, 4 (+8: non-temporal loads), 1 = plain
 SCALAR_VARIANTS = [0, 1, 2, 3, 4, 8, 10, 11, 12]
+# the same chunked kernel reading one row's indices per block of 64 rows that repeat a pattern
+SCALAR_PATTERN_VARIANTS = [16, 17, 18, 20, 21, 22]
 
 
 @pytest.mark.parametrize("alignment", [1, 4])
@@ -73,11 +75,11 @@ def test_csr_scalar_variants_all_bitwise(orc, g, alignment):
     y32 = orc.mult_csr_base_f32(csr[0], csr[1], csr[2].astype(np.float32), x32)
     for dtype, xin, want in ((S.F64, g["x"], g["y_csr_base"]), (S.F32, x32.astype(np.float64), y32)):
         m = Matrix.csr(rows, cols, coo_of(g), alignment, dtype, S.CSR_SCALAR)
-        for v in SCALAR_VARIANTS:
+        for v in SCALAR_VARIANTS + SCALAR_PATTERN_VARIANTS:
             m.set_option("variant", v)
             y = m.mult(xin)
             assert bits_equal(y.astype(want.dtype), want), (v, dtype)
-        assert m.analyze(2) in SCALAR_VARIANTS
+        assert m.analyze(2) in SCALAR_VARIANTS + SCALAR_PATTERN_VARIANTS
         assert bits_equal(m.mult(xin).astype(want.dtype), want)
         with pytest.raises(S.SpmvHipError, match="variant"):
             m.set_option("variant", 99)
@@ -546,3 +548,25 @@ def test_errors_are_reported_not_fatal():
         Matrix.sellp(2, 2, rp, cj, va, S.F64, 3)
     with pytest.raises(S.SpmvHipError, match="tile size"):
         Matrix.csr_merge(2, 2, S.make_coo([0, 1], [0, 1], [1.0, 2.0]), S.F64, 1000)
+
+
+def test_csr_scalar_pattern_blocks_on_grids_and_bands(orc):
+    """Blocks of 64 rows that repeat one pattern (grid interiors, bands) take the index-free path,
+    blocks that do not (boundaries, the ragged last block) the ordinary one, in one launch; hot_columns
+    relabels the columns and must fall back to reading every index."""
+    for gen in (lambda: G.laplacian2d(200), lambda: G.stencil27(20, 21, 22), lambda: G.band(5000, 7, seed=2),
+                lambda: G.band(64 * 40 + 13, 33, seed=3)):
+        rows, cols, rp, cj, va = gen()
+        rp, cj, va = rp.numpy().astype(np.int32), cj.numpy().astype(np.int32), va.numpy().astype(np.float64)
+        x = np.random.default_rng(1).standard_normal(cols)
+        want = orc.mult_csr_base(rp, cj, va, x)
+        coo = S.make_coo(np.repeat(np.arange(rows, dtype=np.int32), np.diff(rp)), cj, va)
+        m = Matrix.csr(rows, cols, coo, 1, S.F64, S.CSR_SCALAR)
+        for v in SCALAR_PATTERN_VARIANTS:
+            m.set_option("variant", v)
+            assert bits_equal(m.mult(x), want), v
+        m.set_option("hot_columns", 1)
+        assert bits_equal(m.mult(x), want)
+        m.set_option("hot_columns", 0)
+        assert bits_equal(m.mult(x), want)
+        m.free()
