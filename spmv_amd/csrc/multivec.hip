@@ -15,6 +15,8 @@
 #include "internal.h"
 #include "device_utils.h"
 
+#include <climits>
+
 namespace spmv {
 
 template <typename T, bool NT> __device__ __forceinline__ T stream_load(const T *p)
@@ -23,12 +25,14 @@ template <typename T, bool NT> __device__ __forceinline__ T stream_load(const T 
 }
 
 // One wave per slice, lane = row; U columns of the slice are loaded per batch and used for all NV
-// vectors before the next batch.
+// vectors before the next batch.  Where the build pass found a slice column to run along a diagonal
+// (sdiag: col - row of all its entries, INT_MIN otherwise; may be null) its indices are not read.
 template <typename T, bool PERM, int NV, int U, bool NT>
-__global__ __launch_bounds__(kBlock) void sliced64_mv_kernel(int rows, int nslices,
+__global__ __launch_bounds__(kBlock) void sliced64_mv_kernel(int rows, int cols, int nslices,
                                                              const int64_t *__restrict__ slice_ptr,
                                                              const int *__restrict__ row_order,
                                                              const unsigned char *__restrict__ slice_ident,
+                                                             const int *__restrict__ sdiag,
                                                              const int *__restrict__ scol,
                                                              const T *__restrict__ sval,
                                                              const T *__restrict__ x, int64_t ldx,
@@ -42,6 +46,15 @@ __global__ __launch_bounds__(kBlock) void sliced64_mv_kernel(int rows, int nslic
     const int width = (int)((slice_ptr[s + 1] - base) >> 6);
     const T *v = sval + base + lane;
     const int *c = scol + base + lane;
+    const int r = s * kWave + lane;
+    const int row = r < rows ? (PERM && !slice_ident[s] ? row_order[r] : r) : 0;
+    const int *dg = sdiag ? sdiag + (base >> 6) : nullptr;
+    const int last = cols - 1;
+    // the index of entry j of this lane's row: computed for a diagonal column, loaded otherwise
+    auto column = [&](int jj) {
+        const int d = dg ? __builtin_amdgcn_readfirstlane(dg[jj]) : INT_MIN;
+        return d != INT_MIN ? min(max(row + d, 0), last) : stream_load<int, NT>(c + (int64_t)jj * kWave);
+    };
     T acc[NV];
 #pragma unroll
     for (int k = 0; k < NV; k++) acc[k] = 0;
@@ -50,9 +63,9 @@ __global__ __launch_bounds__(kBlock) void sliced64_mv_kernel(int rows, int nslic
         int cc[U];
         T vv[U], xx[NV][U];
 #pragma unroll
-        for (int u = 0; u < U; u++) cc[u] = stream_load<int, NT>(c + (int64_t)(j + u) * kWave);
-#pragma unroll
         for (int u = 0; u < U; u++) vv[u] = stream_load<T, NT>(v + (int64_t)(j + u) * kWave);
+#pragma unroll
+        for (int u = 0; u < U; u++) cc[u] = column(j + u);
 #pragma unroll
         for (int k = 0; k < NV; k++)
 #pragma unroll
@@ -63,16 +76,14 @@ __global__ __launch_bounds__(kBlock) void sliced64_mv_kernel(int rows, int nslic
             for (int u = 0; u < U; u++) acc[k] = fma_t(xx[k][u], vv[u], acc[k]);
     }
     for (; j < width; j++) {
-        const int cc = stream_load<int, NT>(c + (int64_t)j * kWave);
+        const int cc = column(j);
         const T vv = stream_load<T, NT>(v + (int64_t)j * kWave);
 #pragma unroll
         for (int k = 0; k < NV; k++) acc[k] = fma_t(x[k * ldx + cc], vv, acc[k]);
     }
-    const int r = s * kWave + lane;
     if (r < rows) {
-        const int dst = PERM && !slice_ident[s] ? row_order[r] : r;
 #pragma unroll
-        for (int k = 0; k < NV; k++) y[k * ldy + dst] = acc[k];
+        for (int k = 0; k < NV; k++) y[k * ldy + row] = acc[k];
     }
 }
 
@@ -244,12 +255,16 @@ static int launch_block(const spmv_hip_matrix *m, const T *x, int64_t ldx, T *y,
         const T *sv = (const T *)m->d_sval;
         if (m->slice_height == kWave) {
             const dim3 grid(blocks_for(m->nslices, kBlock / kWave)), block(kBlock);
+            // the diagonal descriptors pay when at least half the slice columns have one
+            const int *diag = m->d_sdiag && m->diag_columns * 2 * kWave >= m->stored ? m->d_sdiag : nullptr;
             if (perm)
-                hipLaunchKernelGGL((sliced64_mv_kernel<T, true, NV, U, NT>), grid, block, 0, st, m->rows, m->nslices,
-                                   m->d_slice_ptr, m->d_row_order, m->d_slice_ident, m->d_scol, sv, x, ldx, y, ldy);
+                hipLaunchKernelGGL((sliced64_mv_kernel<T, true, NV, U, NT>), grid, block, 0, st, m->rows, m->columns,
+                                   m->nslices, m->d_slice_ptr, m->d_row_order, m->d_slice_ident, diag, m->d_scol, sv, x,
+                                   ldx, y, ldy);
             else
-                hipLaunchKernelGGL((sliced64_mv_kernel<T, false, NV, U, NT>), grid, block, 0, st, m->rows, m->nslices,
-                                   m->d_slice_ptr, m->d_row_order, m->d_slice_ident, m->d_scol, sv, x, ldx, y, ldy);
+                hipLaunchKernelGGL((sliced64_mv_kernel<T, false, NV, U, NT>), grid, block, 0, st, m->rows, m->columns,
+                                   m->nslices, m->d_slice_ptr, m->d_row_order, m->d_slice_ident, diag, m->d_scol, sv, x,
+                                   ldx, y, ldy);
         } else {
             const dim3 grid(blocks_for(m->rows, kBlock)), block(kBlock);
             if (perm)
