@@ -182,6 +182,7 @@ template <typename T, int IPL, int NV, bool NT>
 __global__ __launch_bounds__(kWave) void csr_rows_lds_mv_kernel(int rows, const int *__restrict__ row_ptr,
                                                                 const int *__restrict__ col,
                                                                 const T *__restrict__ val,
+                                                                const unsigned char *__restrict__ pattern_len,
                                                                 const int *__restrict__ row_map,
                                                                 const T *__restrict__ x, int64_t ldx,
                                                                 T *__restrict__ y, int64_t ldy)
@@ -196,6 +197,15 @@ __global__ __launch_bounds__(kWave) void csr_rows_lds_mv_kernel(int rows, const 
     const int re = row < rows ? row_ptr[row + 1] : rs;
     const int run_begin = __builtin_amdgcn_readfirstlane(rs);
     const int run_end = row_ptr[last];
+    // a block whose 64 rows repeat one pattern of L distances from the diagonal (pattern_len, may be
+    // null) reads only its first row's column indices: entry e is row e / L, column row + dist[e % L]
+    __shared__ int dist[32];
+    const int L = pattern_len ? pattern_len[blk] : 0;        // wave-uniform
+    const float inv_len = L ? 1.0f / (float)L : 0.0f;
+    if (L) {
+        if (lane < L) dist[lane] = col[run_begin + lane] - blk * kWave;
+        __syncthreads();
+    }
     T acc[NV];
 #pragma unroll
     for (int k = 0; k < NV; k++) acc[k] = 0;
@@ -203,8 +213,16 @@ __global__ __launch_bounds__(kWave) void csr_rows_lds_mv_kernel(int rows, const 
         int cc[IPL];
         T vv[IPL];
 #pragma unroll
-        for (int i = 0; i < IPL; i++)
-            cc[i] = stream_load<int, NT>(col + min(max(e0 + lane + i * kWave, run_begin), run_end - 1));
+        for (int i = 0; i < IPL; i++) {
+            const int at = min(max(e0 + lane + i * kWave, run_begin), run_end - 1);
+            if (L) {
+                const int rel = at - run_begin;
+                const int r = (int)(((float)rel + 0.5f) * inv_len);      // rel / L, exact for rel < 2048
+                cc[i] = blk * kWave + r + dist[rel - r * L];
+            } else {
+                cc[i] = stream_load<int, NT>(col + at);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < IPL; i++)
             vv[i] = stream_load<T, NT>(val + min(max(e0 + lane + i * kWave, run_begin), run_end - 1));
@@ -246,7 +264,8 @@ static int launch_block(const spmv_hip_matrix *m, const T *x, int64_t ldx, T *y,
     case SPMV_HIP_CSR_MERGE:
     case SPMV_HIP_CSR_BAL:
         hipLaunchKernelGGL((csr_rows_lds_mv_kernel<T, 4, NV, NT>), dim3(blocks_for(m->rows, kWave)), dim3(kWave), 0, st,
-                           m->rows, m->d_row_ptr, m->d_col, (const T *)m->d_val, m->d_row_map, x, ldx, y, ldy);
+                           m->rows, m->d_row_ptr, m->d_col, (const T *)m->d_val,
+                           m->format == SPMV_HIP_CSR_SCALAR ? m->d_block_pat : nullptr, m->d_row_map, x, ldx, y, ldy);
         break;
     case SPMV_HIP_SELL:
     case SPMV_HIP_SELLP:
