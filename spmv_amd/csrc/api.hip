@@ -137,7 +137,7 @@ static int finish_from_device_csr(spmv_hip_matrix *m, int64_t p0, int64_t p1, bo
         // left to the library, rows averaging fewer than 32 entries take the LDS-staged kernel (variant 5)
         if (!p0 && g <= 32) { g = std::min(g, 8); m->variant = 5; }
         m->lanes_per_row = g;
-        return 0;
+        return build_block_patterns(m, st);
     }
     case SPMV_HIP_CSR_MERGE:
         if (normalize_tile_param(p0, 512, &m->items_per_tile)) return 1;

@@ -301,11 +301,13 @@ template <typename T, int IPL, int G, bool NT>
 __global__ __launch_bounds__(kWave) void csr_vector_lds_kernel(int rows, const int *__restrict__ row_ptr,
                                                                const int *__restrict__ col,
                                                                const T *__restrict__ val,
+                                                               const unsigned char *__restrict__ pattern_len,
                                                                const int *__restrict__ row_map,
                                                                const T *__restrict__ x, T *__restrict__ y)
 {
     constexpr int kCap = kWave * IPL, kRowsPerPass = kWave / G;
     __shared__ T prod[kCap];
+    __shared__ int dist[32];
     const int blk = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
     const int lane = threadIdx.x, sub = lane % G;
     const int row = blk * kWave + lane;
@@ -314,6 +316,15 @@ __global__ __launch_bounds__(kWave) void csr_vector_lds_kernel(int rows, const i
     const int re = row < rows ? row_ptr[row + 1] : rs;
     const int run_begin = __builtin_amdgcn_readfirstlane(rs);
     const int run_end = row_ptr[last];
+    // a block whose 64 rows repeat one pattern of L distances from the diagonal (pattern_len, null for the
+    // variants that read every index) takes its column indices from the first row, as in
+    // csr_rows_lds_pat_kernel
+    const int L = pattern_len ? pattern_len[blk] : 0;        // wave-uniform
+    const float inv_len = L ? 1.0f / (float)L : 0.0f;
+    if (L) {
+        if (lane < L) dist[lane] = col[run_begin + lane] - blk * kWave;
+        __syncthreads();
+    }
     int beg[G], end[G];                       // the row this lane helps with in pass p: p * 64/G + lane / G
     T acc[G];
 #pragma unroll
@@ -325,8 +336,14 @@ __global__ __launch_bounds__(kWave) void csr_vector_lds_kernel(int rows, const i
     auto load_chunk = [&](int e0, int (&cc)[IPL], T (&vv)[IPL]) {
 #pragma unroll
         for (int i = 0; i < IPL; i++) {
-            const int *q = col + min(max(e0 + lane + i * kWave, run_begin), run_end - 1);
-            cc[i] = NT ? __builtin_nontemporal_load(q) : *q;
+            const int at = min(max(e0 + lane + i * kWave, run_begin), run_end - 1);
+            if (L) {
+                const int rel = at - run_begin;
+                const int r = (int)(((float)rel + 0.5f) * inv_len);      // rel / L, exact for rel < 2048
+                cc[i] = blk * kWave + r + dist[rel - r * L];
+            } else {
+                cc[i] = NT ? __builtin_nontemporal_load(col + at) : col[at];
+            }
         }
 #pragma unroll
         for (int i = 0; i < IPL; i++) {
@@ -926,17 +943,21 @@ template <typename T> static int launch_csr_vector(const spmv_hip_matrix *m, con
     // rows walked side by side by one lane group: variant 1 -> 1, 2 -> 2, 3 -> 4, 4 -> 8 (never more than
     // the group has lanes); variant 0 -> 4 for groups of 16 lanes and more, else 1 (what measurements favour)
     static const int kRowsOfVariant[] = {0, 1, 2, 4, 8};
-    // variants 5, 6: the LDS-staged kernel for short rows (2, 4 or 8 lanes per row; 6 = non-temporal loads)
-    if (m->variant == 5 || m->variant == 6) {
+    // variants 5, 6: the LDS-staged kernel for short rows (2, 4 or 8 lanes per row; 6 = non-temporal loads);
+    // 7, 8: the same, patterned row blocks reading one row's column indices
+    if (m->variant >= 5 && m->variant <= 8) {
         const dim3 grid(cdiv(rows, kWave)), block(kWave);
         const int g = std::min(m->lanes_per_row, 8);
+        const bool nt = m->variant == 6 || m->variant == 8;
+        const unsigned char *pat = m->variant >= 7 ? m->d_block_pat : nullptr;
+        if (m->variant >= 7 && !pat && m->stored > 0) { set_error("csr_vector: variant %d needs the block patterns", m->variant); return 1; }
 #define SPMV_VECLDS(G)                                                                                \
     case G:                                                                                           \
-        if (m->variant == 5)                                                                          \
-            hipLaunchKernelGGL((csr_vector_lds_kernel<T, 8, G, false>), grid, block, 0, st, rows, rp, cj, va, \
+        if (!nt)                                                                                      \
+            hipLaunchKernelGGL((csr_vector_lds_kernel<T, 8, G, false>), grid, block, 0, st, rows, rp, cj, va, pat, \
                                m->d_row_map, x, y);                                                   \
         else                                                                                          \
-            hipLaunchKernelGGL((csr_vector_lds_kernel<T, 8, G, true>), grid, block, 0, st, rows, rp, cj, va, \
+            hipLaunchKernelGGL((csr_vector_lds_kernel<T, 8, G, true>), grid, block, 0, st, rows, rp, cj, va, pat, \
                                m->d_row_map, x, y);                                                   \
         return 0;
         switch (g) {
@@ -999,6 +1020,10 @@ int variant_candidates(const spmv_hip_matrix *m, int *out, int max_out)
         for (int g = 2; g <= 8; g *= 2)                      // LDS-staged kernel for short rows
             for (int v = 5; v <= 6; v++)
                 if (n < max_out) out[n++] = g + 256 * v;
+        if (m->d_block_pat && !m->d_hot_col && m->pat_blocks * 2 * kWave >= m->rows)
+            for (int g = 2; g <= 8; g *= 2)                  // ... reading one row's indices per patterned block
+                for (int v = 7; v <= 8; v++)
+                    if (n < max_out) out[n++] = g + 256 * v;
     } else if (m->format == SPMV_HIP_CSR_SCALAR) {
         // LDS chunk sizes of the staged lane-per-row kernel (all give the same bits)
         for (int v : {0, 2, 3, 4, 8, 10, 11, 12})
@@ -1279,6 +1304,7 @@ int launch_mult(const spmv_hip_matrix *m, const void *d_x, void *d_y, hipStream_
         view.d_hot_col = nullptr;
         // the block patterns describe the caller's column numbers, not the relabeled ones
         view.d_block_pat = nullptr;
+        if (view.format == SPMV_HIP_CSR_VECTOR && view.variant >= 7) view.variant -= 2;
         if (view.format == SPMV_HIP_CSR_SCALAR && view.variant >= 16) {
             const int plain[] = {0, 2, 3, 3, 8, 10, 11, 11};              // same chunk size (or the next), every index read
             view.variant = plain[(view.variant - 16) & 7];

@@ -109,6 +109,10 @@ def test_csr_vector(orc, g, lanes):
     for v in (5, 6):                                # LDS-staged kernel for short rows (min(lanes, 8) lanes per row)
         m.set_option("variant", v)
         assert rel(orc, m.mult(g["x"]), g["y_csr_base"]) <= TOL_REASSOC, v
+    y5 = m.mult(g["x"])                             # variant 6
+    for v in (7, 8):                                # ... reading one row's indices per patterned block: same sums
+        m.set_option("variant", v)
+        assert bits_equal(m.mult(g["x"]), y5), v
 
 
 @pytest.mark.parametrize("items", [0, 256, 2048])
@@ -561,6 +565,16 @@ def test_csr_scalar_pattern_blocks_on_grids_and_bands(orc):
         x = np.random.default_rng(1).standard_normal(cols)
         want = orc.mult_csr_base(rp, cj, va, x)
         coo = S.make_coo(np.repeat(np.arange(rows, dtype=np.int32), np.diff(rp)), cj, va)
+        mv = Matrix.csr(rows, cols, coo.copy(), 1, S.F64, S.CSR_VECTOR)        # the vector kernel's pattern path
+        mv.set_option("variant", 6)
+        y6 = mv.mult(x)
+        assert orc.rel_l2(y6, want) <= TOL_REASSOC
+        for v in (7, 8):
+            mv.set_option("variant", v)
+            assert bits_equal(mv.mult(x), y6), v
+        mv.set_option("hot_columns", 1)
+        assert bits_equal(mv.mult(x), y6)
+        mv.free()
         m = Matrix.csr(rows, cols, coo, 1, S.F64, S.CSR_SCALAR)
         for v in SCALAR_PATTERN_VARIANTS:
             m.set_option("variant", v)
