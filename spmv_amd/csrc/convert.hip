@@ -45,6 +45,61 @@ __global__ void merge_partition_kernel(int ntiles, int items_per_tile, int n, in
     tile_coord[2 * t + 1] = d - lo;
 }
 
+// tile_pat[t] = L when every row tile t touches (list positions a0..a1) has L entries (1 <= L <= 32) at
+// the same distances from the diagonal and the rows are consecutive; 0 otherwise.  The product kernel
+// then takes the tile's column indices from the first of those rows.  One wave per tile.
+__global__ __launch_bounds__(kWave) void tile_pattern_kernel(int ntiles, int list_len, const int *__restrict__ row_end_list,
+                                                             const int *__restrict__ row_index,
+                                                             const int *__restrict__ tile_coord,
+                                                             const int *__restrict__ col,
+                                                             unsigned char *__restrict__ tile_pat, int *__restrict__ npat)
+{
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const int a0 = tile_coord[2 * t], b0 = tile_coord[2 * t + 1];
+    const int a1 = tile_coord[2 * t + 2], b1 = tile_coord[2 * t + 3];
+    const int hi = min(a1, list_len - 1);
+    int out = 0;
+    if (b1 > b0 && a0 <= hi) {                               // wave-uniform
+        const int start0 = a0 ? row_end_list[a0 - 1] : 0;
+        const int L = row_end_list[a0] - start0;
+        const int row0 = row_index ? row_index[a0] : a0;
+        if (L >= 1 && L <= 32) {
+            bool ok = true;
+            for (int a = a0 + lane; a <= hi && ok; a += kWave) {
+                const int s = a ? row_end_list[a - 1] : 0;
+                const int row = row_index ? row_index[a] : a;
+                ok = row_end_list[a] - s == L && row == row0 + (a - a0);
+                for (int k = 0; k < L && ok; k++) ok = col[s + k] - row == col[start0 + k] - row0;
+            }
+            if (!__ballot(!ok)) out = L;
+        }
+    }
+    if (lane == 0) {
+        tile_pat[t] = (unsigned char)out;
+        if (out) atomicAdd(npat, 1);
+    }
+}
+
+static int build_tile_patterns(spmv_hip_matrix *m, int list_len, const int *list, const int *index, hipStream_t st)
+{
+    if (m->ntiles == 0) return 0;
+    int *d_count = nullptr, count = 0;
+    if (dev_alloc(m, &m->d_tile_pat, (size_t)m->ntiles)) return 1;
+    if (dev_alloc<int>(nullptr, &d_count, 1)) return 1;
+    bool ok = hipMemsetAsync(d_count, 0, sizeof(int), st) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(tile_pattern_kernel, dim3((unsigned)m->ntiles), dim3(kWave), 0, st, m->ntiles, list_len, list,
+                           index, m->d_tile_coord, m->d_col, m->d_tile_pat, d_count);
+        ok = hipGetLastError() == hipSuccess &&
+             hipMemcpyAsync(&count, d_count, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess &&
+             hipStreamSynchronize(st) == hipSuccess;
+    }
+    (void)hipFree(d_count);
+    if (!ok) { set_error("tiles: scanning for row patterns failed"); return 1; }
+    m->pat_tiles = count;
+    return 0;
+}
+
 int build_merge_tiles(spmv_hip_matrix *m, hipStream_t st)
 {
     int64_t items = (int64_t)m->rows + m->stored;
@@ -57,7 +112,7 @@ int build_merge_tiles(spmv_hip_matrix *m, hipStream_t st)
                        m->items_per_tile, m->rows, (int)m->stored, m->d_row_ptr + 1, m->d_tile_coord);
     SPMV_HIP_TRY(hipGetLastError(), return 1);
     SPMV_HIP_TRY(hipStreamSynchronize(st), return 1);
-    return 0;
+    return build_tile_patterns(m, m->rows, m->d_row_ptr + 1, nullptr, st);
 }
 
 // ------------------------------------------------------------ balanced CSR ----
@@ -135,6 +190,7 @@ int build_bal_tiles(spmv_hip_matrix *m, hipStream_t st)
                            m->nz_rows, m->d_nzr_end, m->d_tile_coord);
         SPMV_HIP_TRY(hipGetLastError(), break);
         SPMV_HIP_TRY(hipStreamSynchronize(st), break);
+        if (build_tile_patterns(m, m->nz_rows, m->d_nzr_end, m->d_nzr_id, st)) break;
         rc = 0;
     } while (0);
     if (d_flag) (void)hipFree(d_flag);

@@ -57,6 +57,8 @@ struct spmv_hip_matrix {
     int *d_tile_coord = nullptr;   // 2*(ntiles+1) ints
     int *d_row_carry = nullptr;    // ntiles
     void *d_val_carry = nullptr;   // ntiles (dtype)
+    unsigned char *d_tile_pat = nullptr; // ntiles: the common row length when all rows of the tile repeat one pattern
+    int pat_tiles = 0;             // how many tiles do
     // balanced CSR: compacted non-empty rows
     int nz_rows = 0;               // number of non-empty rows
     int *d_nzr_id = nullptr;       // [nz_rows] original row index

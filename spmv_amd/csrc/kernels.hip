@@ -759,6 +759,7 @@ template <typename T, int IPL, int MODE>
 __global__ __launch_bounds__(kWave) void wave_tile_kernel(int list_len, const int *__restrict__ row_end_list,
                                                           const int *__restrict__ row_index,
                                                           const int *__restrict__ tile_coord,
+                                                          const unsigned char *__restrict__ tile_pat,
                                                           const int *__restrict__ col,
                                                           const T *__restrict__ val,
                                                           const T *__restrict__ x, T *__restrict__ y,
@@ -767,6 +768,7 @@ __global__ __launch_bounds__(kWave) void wave_tile_kernel(int list_len, const in
     constexpr int kCap = kWave * IPL;
     __shared__ T prod[kCap];
     __shared__ int rend[kCap];
+    __shared__ int dist[32];
     const int t = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
     const int lane = threadIdx.x;
     const int a0 = tile_coord[2 * t], b0 = tile_coord[2 * t + 1];
@@ -780,13 +782,31 @@ __global__ __launch_bounds__(kWave) void wave_tile_kernel(int list_len, const in
     constexpr int kLoads = MODE ? IPL + 1 : IPL;
     const int first = MODE ? (b0 & ~31) - b0 : 0;   // position of lane 0's first load relative to the tile
     T pp[kLoads];
+    // a tile whose rows repeat one pattern of L distances from the diagonal (tile_pat, null for the
+    // variants that read every index) takes its column indices from its first row: the entry at
+    // position p of the arrays is entry (p - start0) % L of row row0 + (p - start0) / L
+    const int L = tile_pat ? tile_pat[t] : 0;                // wave-uniform
+    int start0 = 0, row0 = 0;
+    if (L) {
+        start0 = a0 ? row_end_list[a0 - 1] : 0;
+        row0 = row_index ? row_index[a0] : a0;
+        if (lane < L) dist[lane] = col[start0 + lane] - row0;
+        __syncthreads();
+    }
+    const float inv_len = L ? 1.0f / (float)L : 0.0f;
     if (nz > 0) {
         int cc[kLoads];
         T vv[kLoads], xx[kLoads];
 #pragma unroll
         for (int i = 0; i < kLoads; i++) {
-            const int *p = col + b0 + min(max(first + lane + i * kWave, 0), nz - 1);
-            cc[i] = MODE == 2 ? __builtin_nontemporal_load(p) : *p;
+            const int k = min(max(first + lane + i * kWave, 0), nz - 1);
+            if (L) {
+                const int rel = b0 + k - start0;
+                const int r = (int)(((float)rel + 0.5f) * inv_len);      // rel / L, exact for rel < 4096
+                cc[i] = row0 + r + dist[rel - r * L];
+            } else {
+                cc[i] = MODE == 2 ? __builtin_nontemporal_load(col + b0 + k) : col[b0 + k];
+            }
         }
 #pragma unroll
         for (int i = 0; i < kLoads; i++) {
@@ -1035,6 +1055,7 @@ int variant_candidates(const spmv_hip_matrix *m, int *out, int max_out)
     } else if (m->format == SPMV_HIP_CSR_MERGE || m->format == SPMV_HIP_CSR_BAL) {
         for (int v : {0, 1})
             if (n < max_out) out[n++] = v;
+        if (m->d_tile_pat && !m->d_hot_col && m->pat_tiles * 2 >= m->ntiles && n < max_out) out[n++] = 2;
     } else if (n < max_out) {
         out[n++] = 0;
     }
@@ -1192,17 +1213,20 @@ template <typename T> static int launch_tiles(const spmv_hip_matrix *m, const T 
         if (!bal && m->rows > 0) SPMV_HIP_TRY(hipMemsetAsync(y, 0, (size_t)m->rows * sizeof(T), st), return 1);
         return 0;
     }
-    // variant 0: loads start at the tile's first entry; 1: line-aligned non-temporal loads (MODE 2)
-    if (m->variant != 0 && m->variant != 1) { set_error("tile kernel: unknown kernel variant %d", m->variant); return 1; }
+    // variant 0: loads start at the tile's first entry; 1: line-aligned non-temporal loads (MODE 2); 2: as 1,
+    // patterned tiles reading one row's column indices
+    if (m->variant < 0 || m->variant > 2) { set_error("tile kernel: unknown kernel variant %d", m->variant); return 1; }
+    if (m->variant == 2 && !m->d_tile_pat) { set_error("tile kernel: variant 2 needs the tile patterns"); return 1; }
+    const unsigned char *pat = m->variant == 2 ? m->d_tile_pat : nullptr;
     // merge tiles hold items_per_tile path items; balanced tiles hold that many non-zeros
 #define SPMV_WTILE_CASE(I)                                                                              \
     case I:                                                                                              \
         if (m->variant == 0)                                                                             \
             hipLaunchKernelGGL((wave_tile_kernel<T, I, 0>), dim3(m->ntiles), dim3(kWave), 0, st, list_len, list, \
-                               index, m->d_tile_coord, m->d_col, va, x, y, m->d_row_carry, vc);          \
+                               index, m->d_tile_coord, pat, m->d_col, va, x, y, m->d_row_carry, vc);     \
         else                                                                                             \
             hipLaunchKernelGGL((wave_tile_kernel<T, I, 2>), dim3(m->ntiles), dim3(kWave), 0, st, list_len, list, \
-                               index, m->d_tile_coord, m->d_col, va, x, y, m->d_row_carry, vc);          \
+                               index, m->d_tile_coord, pat, m->d_col, va, x, y, m->d_row_carry, vc);     \
         break;
     switch (m->items_per_tile % kWave ? 0 : m->items_per_tile / kWave) {
         SPMV_WTILE_CASE(4)
@@ -1305,6 +1329,8 @@ int launch_mult(const spmv_hip_matrix *m, const void *d_x, void *d_y, hipStream_
         // the block patterns describe the caller's column numbers, not the relabeled ones
         view.d_block_pat = nullptr;
         if (view.format == SPMV_HIP_CSR_VECTOR && view.variant >= 7) view.variant -= 2;
+        view.d_tile_pat = nullptr;
+        if ((view.format == SPMV_HIP_CSR_MERGE || view.format == SPMV_HIP_CSR_BAL) && view.variant == 2) view.variant = 1;
         if (view.format == SPMV_HIP_CSR_SCALAR && view.variant >= 16) {
             const int plain[] = {0, 2, 3, 3, 8, 10, 11, 11};              // same chunk size (or the next), every index read
             view.variant = plain[(view.variant - 16) & 7];

@@ -79,6 +79,9 @@ def test_every_format_on_random_shapes(orc, seed):
             assert orc.rel_l2(y, want) <= 1e-13, (name, seed)
         m.analyze(1)                                 # whatever variant wins must still be right
         assert orc.rel_l2(m.mult(x), want) <= 1e-13, (name, seed, m.info.variant)
+        if name.startswith(("csr_merge", "csr_bal")) and nnz:     # patterned-tile kernel
+            m.set_option("variant", 2)
+            assert orc.rel_l2(m.mult(x), want) <= 1e-13, (name, seed, 2)
         if name == "csr_scalar":                                   # patterned-block kernels
             for v in (16, 22):
                 m.set_option("variant", v)

@@ -132,8 +132,12 @@ def test_csr_merge(orc, g, items):
     assert rel(orc, y, g["y_csr_base"]) <= TOL_REASSOC
     assert rel(orc, y, g["y_csr_merge_t8"]) <= TOL_REASSOC
     m.set_option("variant", 1)                      # line-aligned non-temporal loads
-    assert rel(orc, m.mult(g["x"]), g["y_csr_base"]) <= TOL_REASSOC
-    assert m.analyze(2) in (0, 1)
+    y1 = m.mult(g["x"])
+    assert rel(orc, y1, g["y_csr_base"]) <= TOL_REASSOC
+    if len(g["csr1_col"]):
+        m.set_option("variant", 2)                  # patterned tiles read one row's indices: same sums
+        assert bits_equal(m.mult(g["x"]), y1)
+    assert m.analyze(2) in (0, 1, 2)
     with pytest.raises(S.SpmvHipError, match="variant"):
         m.set_option("variant", 7)
         m.mult(g["x"])
@@ -148,7 +152,11 @@ def test_csr_bal_handles_empty_rows_too(orc, g, chunk):
     if "y_csr_bal_t8" in g:
         assert rel(orc, y, g["y_csr_bal_t8"]) <= TOL_REASSOC
     m.set_option("variant", 1)
-    assert rel(orc, m.mult(g["x"]), g["y_csr_base"]) <= TOL_REASSOC
+    y1 = m.mult(g["x"])
+    assert rel(orc, y1, g["y_csr_base"]) <= TOL_REASSOC
+    if len(g["csr1_col"]):
+        m.set_option("variant", 2)
+        assert bits_equal(m.mult(g["x"]), y1)
 
 
 def test_csr_vector_analyze_picks_a_group_size(orc, g):
@@ -565,6 +573,17 @@ def test_csr_scalar_pattern_blocks_on_grids_and_bands(orc):
         x = np.random.default_rng(1).standard_normal(cols)
         want = orc.mult_csr_base(rp, cj, va, x)
         coo = S.make_coo(np.repeat(np.arange(rows, dtype=np.int32), np.diff(rp)), cj, va)
+        for make in (Matrix.csr_merge, Matrix.csr_bal):                         # the tile kernels' pattern path
+            for items in (0, 2048):
+                mt = make(rows, cols, coo.copy(), S.F64, items)
+                mt.set_option("variant", 1)
+                y1 = mt.mult(x)
+                assert orc.rel_l2(y1, want) <= TOL_REASSOC
+                mt.set_option("variant", 2)
+                assert bits_equal(mt.mult(x), y1)
+                mt.set_option("hot_columns", 1)
+                assert bits_equal(mt.mult(x), y1)
+                mt.free()
         mv = Matrix.csr(rows, cols, coo.copy(), 1, S.F64, S.CSR_VECTOR)        # the vector kernel's pattern path
         mv.set_option("variant", 6)
         y6 = mv.mult(x)
