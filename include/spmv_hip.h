@@ -247,11 +247,16 @@ int spmv_hip_scale_dev(int n, const void *d_y, void *d_x, int dtype, const doubl
 int spmv_hip_set_option(spmv_hip_matrix *m, const char *name, int64_t value);
 /* sellcs_analyze_matrix (sell.c:30, sellcs_analyzer.c:46-120) re-thought for the
  * GPU: times every kernel variant of the handle's format `reps` times on a
- * zero vector and keeps the fastest.  Variant 0 of the sliced formats keeps
- * mult_csr_base's summation order (bit-identical y); the others reassociate.
- * All CSR_SCALAR variants (LDS chunk sizes) give the same bits.  For CSR_VECTOR
- * the trial covers lanes per row x rows walked side by side per lane group, and
- * the LDS-staged kernel for short rows (variants 5, 6). */
+ * zero vector and keeps the fastest.  Variants 0 and 16..23 of the sliced
+ * formats keep mult_csr_base's summation order (bit-identical y); 1..12 (16-byte
+ * loads) reassociate.  All CSR_SCALAR variants (LDS chunk sizes) give the same
+ * bits.  For CSR_VECTOR the trial covers lanes per row x rows walked side by
+ * side per lane group, and the LDS-staged kernel for short rows (variants 5..8).
+ * Where the matrix has regular structure the trial includes the variants that
+ * do not read column indices they can compute -- slice columns at one distance
+ * from the diagonal (sliced formats, 16..23), blocks of 64 rows or whole tiles
+ * that repeat one row pattern (CSR_SCALAR 16..22, CSR_VECTOR 7..8, merge-path
+ * and balanced tiles 2); each gives the bits of its index-reading twin. */
 int spmv_hip_analyze(spmv_hip_matrix *m, int reps);
 
 /* ---- introspection for layout-parity tests ---------------------------------- */
