@@ -603,3 +603,22 @@ def test_csr_scalar_pattern_blocks_on_grids_and_bands(orc):
         m.set_option("hot_columns", 0)
         assert bits_equal(m.mult(x), want)
         m.free()
+        # fp32: each index-skipping variant against its index-reading twin, and the scalar one against the oracle
+        x32 = x.astype(np.float32)
+        want32 = orc.mult_csr_base_f32(rp, cj, va.astype(np.float32), x32)
+        xin = x32.astype(np.float64)
+        m = Matrix.csr(rows, cols, coo.copy(), 1, S.F32, S.CSR_SCALAR)
+        for v in (16, 22):
+            m.set_option("variant", v)
+            assert bits_equal(m.mult(xin).astype(np.float32), want32), v
+        m.free()
+        for build, twin, skipping in ((lambda: Matrix.csr(rows, cols, coo.copy(), 1, S.F32, S.CSR_VECTOR), 6, 8),
+                                      (lambda: Matrix.csr_merge(rows, cols, coo.copy(), S.F32), 1, 2),
+                                      (lambda: Matrix.csr_bal(rows, cols, coo.copy(), S.F32), 1, 2)):
+            m = build()
+            m.set_option("variant", twin)
+            y_twin = m.mult(xin)
+            assert orc.rel_l2(y_twin, want32.astype(np.float64)) <= TOL_F32_VS_F32
+            m.set_option("variant", skipping)
+            assert bits_equal(m.mult(xin), y_twin), skipping
+            m.free()
