@@ -254,7 +254,7 @@ int spmv_hip_set_option(spmv_hip_matrix *m, const char *name, int64_t value);
  * side per lane group, and the LDS-staged kernel for short rows (variants 5..8).
  * Where the matrix has regular structure the trial includes the variants that
  * do not read column indices they can compute -- slice columns at one distance
- * from the diagonal (sliced formats, 16..23), blocks of 64 rows or whole tiles
+ * from the diagonal (sliced formats 16..23, padding-free SELL 9..12), blocks of 64 rows or whole tiles
  * that repeat one row pattern (CSR_SCALAR 16..22, CSR_VECTOR 7..8, merge-path
  * and balanced tiles 2); each gives the bits of its index-reading twin. */
 int spmv_hip_analyze(spmv_hip_matrix *m, int reps);

@@ -454,6 +454,35 @@ __global__ __launch_bounds__(kWave) void dfc_fill_kernel(int rows, const int *__
     }
 }
 
+// The padding-free layout's counterpart of slice_diag_kernel: diag[first column of slice s + j] = the
+// distance col - row shared by the active lanes of column j, or INT_MIN.  One wave per slice.
+__global__ __launch_bounds__(kWave) void dfc_diag_kernel(int rows, int nslices, const int *__restrict__ sorted_len,
+                                                         const int *__restrict__ row_order,
+                                                         const int64_t *__restrict__ slice_ptr,
+                                                         const int64_t *__restrict__ vop_ptr,
+                                                         const int *__restrict__ scol, int *__restrict__ diag,
+                                                         unsigned long long *__restrict__ ndiag)
+{
+    const int s = blockIdx.x, lane = threadIdx.x;
+    if (s >= nslices) return;
+    const int r = s * kWave + lane;
+    const int len = r < rows ? sorted_len[r] : 0;
+    const int row = r < rows ? row_order[r] : 0;
+    const int width = __builtin_amdgcn_readfirstlane(len);      // lane 0 holds the slice's longest row
+    const int64_t base = slice_ptr[s], vp = vop_ptr[s];
+    int run = 0, found = 0;
+    for (int j = 0; j < width; j++) {
+        const bool real = j < len;
+        const int d = real ? scol[base + run + lane] - row : 0;
+        const int d0 = __builtin_amdgcn_readfirstlane(d);
+        const int out = __ballot(real && d != d0) ? INT_MIN : d0;
+        if (lane == 0) diag[vp + j] = out;
+        found += out != INT_MIN;
+        run += __popcll(__ballot(real));
+    }
+    if (lane == 0 && found) atomicAdd(ndiag, (unsigned long long)found);
+}
+
 int build_sell_dfc(spmv_hip_matrix *m, const int *d_row_ptr, const int *d_col, const void *d_val,
                    bool val_is_f64, hipStream_t st)
 {
@@ -518,6 +547,24 @@ int build_sell_dfc(spmv_hip_matrix *m, const int *d_row_ptr, const int *d_col, c
                                    (const float *)d_val, m->d_row_order, m->d_sorted_len, m->d_slice_ptr, m->d_scol,
                                    (float *)m->d_sval);
             SPMV_HIP_TRY(hipGetLastError(), break);
+        }
+        if (vops > 0) {
+            // one number per column: the distance of its entries from the diagonal, where they share one
+            unsigned long long *d_count = nullptr, count = 0;
+            if (dev_alloc(m, &m->d_sdiag, (size_t)vops)) break;
+            if (dev_alloc<unsigned long long>(nullptr, &d_count, 1)) break;
+            bool ok = hipMemsetAsync(d_count, 0, sizeof count, st) == hipSuccess;
+            if (ok) {
+                hipLaunchKernelGGL(dfc_diag_kernel, dim3((unsigned)m->nslices), dim3(kWave), 0, st, rows, m->nslices,
+                                   m->d_sorted_len, m->d_row_order, m->d_slice_ptr, m->d_vop_ptr, m->d_scol, m->d_sdiag,
+                                   d_count);
+                ok = hipGetLastError() == hipSuccess &&
+                     hipMemcpyAsync(&count, d_count, sizeof count, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                     hipStreamSynchronize(st) == hipSuccess;
+            }
+            (void)hipFree(d_count);
+            if (!ok) { set_error("sell_dfc: scanning the columns for diagonals failed"); break; }
+            m->diag_columns = (int64_t)count;
         }
         SPMV_HIP_TRY(hipStreamSynchronize(st), break);
         rc = 0;

@@ -565,14 +565,19 @@ __global__ __launch_bounds__(kBlock) void sliced64_diag_kernel(int rows, int col
 // column is one contiguous run starting where the previous column ended.  The run start is carried
 // as a wave-uniform counter (ballot + popcount), so neither vop_len nor vop_ptr is read here.  One
 // fma per entry in ascending column order: the summation order of mult_csr_base (csr.c:4-13).
-template <typename T, int U, bool NT>
+// DIAG: columns whose active lanes all sit at one distance from the diagonal (sdiag, one int per
+// column, INT_MIN otherwise; vop_ptr = first column of each slice) are gathered as x[row + d]
+// without reading their indices.
+template <typename T, int U, bool NT, bool DIAG = false>
 __global__ __launch_bounds__(kBlock) void sell_dfc_kernel(int rows, int nslices,
                                                           const int64_t *__restrict__ slice_ptr,
                                                           const int *__restrict__ sorted_len,
                                                           const int *__restrict__ row_order,
                                                           const int *__restrict__ scol,
                                                           const T *__restrict__ sval,
-                                                          const T *__restrict__ x, T *__restrict__ y)
+                                                          const T *__restrict__ x, T *__restrict__ y,
+                                                          const int64_t *__restrict__ vop_ptr = nullptr,
+                                                          const int *__restrict__ sdiag = nullptr)
 {
     unsigned b = xcd_contiguous_block(blockIdx.x, gridDim.x);
     int s = __builtin_amdgcn_readfirstlane((int)(b * (kBlock / kWave) + threadIdx.x / kWave));
@@ -584,6 +589,8 @@ __global__ __launch_bounds__(kBlock) void sell_dfc_kernel(int rows, int nslices,
     const int *c = scol + slice_ptr[s] + lane;
     const T *v = sval + slice_ptr[s] + lane;
     const int shortest = __builtin_amdgcn_readlane(len, kWave - 1);   // columns below it hold all 64 lanes
+    const int row = DIAG && r < rows ? row_order[r] : 0;
+    const int *dg = DIAG ? sdiag + vop_ptr[s] : nullptr;
     int run = 0;                                                // entries of the slice before column j
     T acc = 0;
     int j0 = 0;
@@ -591,7 +598,11 @@ __global__ __launch_bounds__(kBlock) void sell_dfc_kernel(int rows, int nslices,
         int cc[U];
         T vv[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) cc[u] = NT ? __builtin_nontemporal_load(c + run + u * kWave) : c[run + u * kWave];
+        for (int u = 0; u < U; u++) {
+            const int d = DIAG ? __builtin_amdgcn_readfirstlane(dg[j0 + u]) : INT_MIN;
+            if (d != INT_MIN) cc[u] = row + d;
+            else cc[u] = NT ? __builtin_nontemporal_load(c + run + u * kWave) : c[run + u * kWave];
+        }
 #pragma unroll
         for (int u = 0; u < U; u++) vv[u] = NT ? __builtin_nontemporal_load(v + run + u * kWave) : v[run + u * kWave];
 #pragma unroll
@@ -607,8 +618,11 @@ __global__ __launch_bounds__(kBlock) void sell_dfc_kernel(int rows, int nslices,
             run += __popcll(__ballot(j0 + u < len));
         }
 #pragma unroll
-        for (int u = 0; u < U; u++)
-            cc[u] = j0 + u < len ? (NT ? __builtin_nontemporal_load(c + off[u]) : c[off[u]]) : 0;
+        for (int u = 0; u < U; u++) {
+            const int d = DIAG && j0 + u < width ? __builtin_amdgcn_readfirstlane(dg[j0 + u]) : INT_MIN;
+            if (d != INT_MIN) cc[u] = j0 + u < len ? row + d : 0;
+            else cc[u] = j0 + u < len ? (NT ? __builtin_nontemporal_load(c + off[u]) : c[off[u]]) : 0;
+        }
 #pragma unroll
         for (int u = 0; u < U; u++)
             vv[u] = j0 + u < len ? (NT ? __builtin_nontemporal_load(v + off[u]) : v[off[u]]) : (T)0;
@@ -618,7 +632,7 @@ __global__ __launch_bounds__(kBlock) void sell_dfc_kernel(int rows, int nslices,
             if (j0 + u < len) acc = fma_t(xv, vv[u], acc);
         }
     }
-    if (r < rows) y[row_order[r]] = acc;
+    if (r < rows) y[DIAG ? row : row_order[r]] = acc;
 }
 
 // The same product with the partial columns staged through LDS.  The columns below the slice's
@@ -1025,6 +1039,9 @@ int variant_candidates(const spmv_hip_matrix *m, int *out, int max_out)
     if (m->format == SPMV_HIP_SELL_DFC) {
         for (int v = 0; v <= 8; v++)                          // see launch_sell_dfc
             if (n < max_out) out[n++] = v;
+        if (m->d_sdiag && m->diag_columns * 2 >= m->vops)
+            for (int v = 9; v <= 12; v++)
+                if (n < max_out) out[n++] = v;
     } else if (sliced64) {
         for (int v : kSlicedVariants)
             if (n < max_out) out[n++] = v;
@@ -1119,9 +1136,20 @@ template <typename T> static int launch_sell_dfc(const spmv_hip_matrix *m, const
         hipLaunchKernelGGL((sell_dfc_lds_kernel<T, I, NT>), dim3((unsigned)m->nslices), dim3(kWave), 0, st, m->rows, \
                            m->nslices, m->d_slice_ptr, m->d_sorted_len, m->d_row_order, m->d_scol, sv, x, y); \
         break;
+#define SPMV_DFC_DIAG(V, U, NT)                                                                          \
+    case V:                                                                                              \
+        if (!m->d_sdiag) { set_error("sell_dfc: variant %d needs the diagonal descriptors", V); return 1; } \
+        hipLaunchKernelGGL((sell_dfc_kernel<T, U, NT, true>), grid, block, 0, st, m->rows, m->nslices, m->d_slice_ptr, \
+                           m->d_sorted_len, m->d_row_order, m->d_scol, sv, x, y, m->d_vop_ptr, m->d_sdiag); \
+        break;
     // 0..4: partial columns as masked loads (8, 16, 8 nt, 16 nt, 4 columns per batch);
-    // 5..8: partial columns staged through LDS (chunks of 512, 512 nt, 256, 1024 entries)
-    switch (m->variant) {
+    // 5..8: partial columns staged through LDS (chunks of 512, 512 nt, 256, 1024 entries);
+    // 9..12: as 0..3, the indices of columns along a diagonal not read
+    switch (m->stored == 0 && m->variant >= 9 && m->variant <= 12 ? 0 : m->variant) {
+        SPMV_DFC_DIAG(9, 8, false)
+        SPMV_DFC_DIAG(10, 16, false)
+        SPMV_DFC_DIAG(11, 8, true)
+        SPMV_DFC_DIAG(12, 16, true)
         SPMV_DFC(0, 8, false)
         SPMV_DFC(1, 16, false)
         SPMV_DFC(2, 8, true)
@@ -1135,6 +1163,7 @@ template <typename T> static int launch_sell_dfc(const spmv_hip_matrix *m, const
     }
 #undef SPMV_DFC_LDS
 #undef SPMV_DFC
+#undef SPMV_DFC_DIAG
     return 0;
 }
 

@@ -86,6 +86,10 @@ def test_every_format_on_random_shapes(orc, seed):
             for v in (16, 22):
                 m.set_option("variant", v)
                 assert bits_equal(m.mult(x), want), (name, seed, v)
+        if name == "sell_dfc" and nnz:
+            for v in (9, 12):
+                m.set_option("variant", v)
+                assert bits_equal(m.mult(x), want), (name, seed, v)
         if name in ("sell_64", "sell_1024", "sellp", "ell"):      # diagonal-column kernels (clamped padding lanes)
             for v in (16, 22):
                 m.set_option("variant", v)

@@ -197,15 +197,18 @@ def test_sell_dfc_layout_and_product(orc, g, sigma):
     assert bits_equal(m.download(S.ARR_SLICE_PTR), want["slice_ptr"])
     assert bits_equal(m.download(S.ARR_COL), want["col"])
     assert bits_equal(m.download(S.ARR_VAL), want["val"])
-    for v in range(9):                              # masked-load and LDS-staged handling of the partial columns
-        m.set_option("variant", v)
+    for v in range(13):                             # masked-load and LDS-staged handling of the partial columns;
+        m.set_option("variant", v)                  # 9..12: indices of columns along a diagonal not read
         assert bits_equal(m.mult(g["x"]), g["y_csr_base"]), v
-    assert m.analyze(2) in range(9)
+    assert 0 <= info.diag_columns <= int(want["vop_ptr"][-1])
+    assert m.analyze(2) in range(13)
     m.free()
     x32 = g["x"].astype(np.float32)
     m = Matrix.sell_dfc(rows, cols, *csr, S.F32, 64, sigma)
     y32 = orc.mult_csr_base_f32(csr[0], csr[1], csr[2].astype(np.float32), x32)
-    assert bits_equal(m.mult(x32.astype(np.float64)).astype(np.float32), y32)
+    for v in (0, 9, 12):
+        m.set_option("variant", v)
+        assert bits_equal(m.mult(x32.astype(np.float64)).astype(np.float32), y32), v
     m.free()
 
 
