@@ -9,7 +9,9 @@
 // Summation order per kernel (what the parity tolerance has to cover):
 //   csr_scalar, sliced (lane per row): ascending column position, one fma per
 //     entry -- the order of mult_csr_base (reference csr.c:4-13); bit-identical
-//     to it.
+//     to it.  The variants that compute column indices instead of reading them
+//     (diagonal slice columns, patterned row blocks / tiles) change where an
+//     index comes from, never the order or the operands.
 //   csr_vector: G interleaved partial sums per row + butterfly.
 //   sliced wide variants: 2 (fp64) / 4 (fp32) interleaved partial sums per row.
 //   tile (merge-path / balanced): product rounded, then each row's products
