@@ -112,7 +112,10 @@ static void coo_to_csr(int rows, int nnz, const struct mtx *coo, int **rp, int *
 /* MODE -> handle: the if/else chain of driver_spmv.c:186-261 */
 static spmv_hip_matrix *create_for_mode(const char *mode, int rows, int cols, int nnz, struct mtx *coo, int dtype)
 {
-    if (!strcmp(mode, "csr_base") || !strcmp(mode, "csr_autovec"))
+    /* "coo" (driver_spmv.c:186-188): create_coo sorts by (row, col) and mult_coo (coo.c:3-14) sums each
+     * row's entries in that order from 0.0 -- the sums of mult_csr_base, so it runs on the lane-per-row
+     * CSR kernel */
+    if (!strcmp(mode, "coo") || !strcmp(mode, "csr_base") || !strcmp(mode, "csr_autovec"))
         return spmv_hip_create_csr(rows, cols, nnz, 1, coo, dtype, SPMV_HIP_CSR_SCALAR, 0);
     if (!strcmp(mode, "csr_vec") || !strcmp(mode, "csr_highway"))
         return spmv_hip_create_csr(rows, cols, nnz, REFERENCE_BLOCK, coo, dtype, SPMV_HIP_CSR_VECTOR, 0);
@@ -138,7 +141,7 @@ static spmv_hip_matrix *create_for_mode(const char *mode, int rows, int cols, in
 int main(int argc, char *argv[])
 {
     if (argc != 4) {
-        printf("Usage: spmv_hip [csr_base|csr_vec|csr_merge|csr_bal|sellp_vec|ell|sell|sell_dfc|auto][:f32] <mtx list> <output csv>\n");
+        printf("Usage: spmv_hip [coo|csr_base|csr_vec|csr_merge|csr_bal|sellp_vec|ell|sell|sell_dfc|auto][:f32] <mtx list> <output csv>\n");
         exit(-1);
     }
     char mode[64];

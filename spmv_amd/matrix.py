@@ -248,12 +248,17 @@ def coo_to_csr_host(rows, coo_sorted):
 # reference MODE strings (driver_spmv.c:186-261) and the HIP additions
 REFERENCE_BLOCK = 4  # _BLOCK of the AVX2 build (spmv.h:20-22)
 
-MODES = ("csr_base", "csr_autovec", "csr_vec", "csr_highway", "csr_merge", "csr_bal", "sellp_vec", "sellp_autovec",
+MODES = ("coo", "csr_base", "csr_autovec", "csr_vec", "csr_highway", "csr_merge", "csr_bal", "sellp_vec", "sellp_autovec",
          "sellp_highway", "ell", "sell")
 
 
 def create(mode: str, rows: int, columns: int, coo: np.ndarray, dtype=L.F64, sigma=0) -> Matrix:
     """MODE -> creator, as the reference driver's if/else chain does."""
+    if mode == "coo":
+        # :186-188: create_coo sorts by (row, col), mult_coo (coo.c:3-14) sums each row's entries in that
+        # order from 0.0 and stores the sum -- the sums of mult_csr_base bit for bit, so the MODE runs on
+        # the lane-per-row CSR kernel
+        return Matrix.csr(rows, columns, coo, 1, dtype, L.CSR_SCALAR)
     if mode == "csr_base" or mode == "csr_autovec":          # :192-197
         return Matrix.csr(rows, columns, coo, 1, dtype, L.CSR_SCALAR)
     if mode in ("csr_vec", "csr_highway"):                   # :189-191,198-201 (rows padded to _BLOCK)

@@ -362,6 +362,8 @@ def test_modes_of_the_reference_driver(orc, g):
         m = S.create(mode, rows, cols, coo_of(g, "in"))
         y = m.mult(g["x"])
         assert rel(orc, y, g["y_coo"]) <= TOL_REASSOC, mode
+        if mode == "coo":                           # mult_coo (coo.c:3-14) sums like mult_csr_base: same bits
+            assert bits_equal(y, g["y_coo"])
         m.free()
     with pytest.raises(ValueError):
         S.create("no_such_mode", rows, cols, coo_of(g))

@@ -221,7 +221,7 @@ def test_sort_coo_matches_reference_order(orc):
 
 def test_mode_table_mirrors_reference_driver():
     # MODE strings the reference driver accepts for the formats on this path (driver_spmv.c:186-261)
-    for mode in ("csr_base", "csr_autovec", "csr_vec", "csr_highway", "csr_merge", "csr_bal", "sellp_vec",
+    for mode in ("coo", "csr_base", "csr_autovec", "csr_vec", "csr_highway", "csr_merge", "csr_bal", "sellp_vec",
                  "sellp_autovec", "sellp_highway", "ell", "sell"):
         assert mode in S.MODES
     with pytest.raises(ValueError, match="Unknown execution mode"):
