@@ -1059,7 +1059,7 @@ int variant_candidates(const spmv_hip_matrix *m, int *out, int max_out)
         for (int g = 2; g <= 8; g *= 2)                      // LDS-staged kernel for short rows
             for (int v = 5; v <= 6; v++)
                 if (n < max_out) out[n++] = g + 256 * v;
-        if (m->d_block_pat && !m->d_hot_col && m->pat_blocks * 2 * kWave >= m->rows)
+        if (m->d_block_pat && !m->d_hot_col && (int64_t)m->pat_blocks * 2 * kWave >= m->rows)
             for (int g = 2; g <= 8; g *= 2)                  // ... reading one row's indices per patterned block
                 for (int v = 7; v <= 8; v++)
                     if (n < max_out) out[n++] = g + 256 * v;
@@ -1068,7 +1068,7 @@ int variant_candidates(const spmv_hip_matrix *m, int *out, int max_out)
         for (int v : {0, 2, 3, 4, 8, 10, 11, 12})
             if (n < max_out) out[n++] = v;
         // the kernels that read one row's indices per patterned block, when at least half the blocks are
-        if (m->d_block_pat && !m->d_hot_col && m->pat_blocks * 2 * kWave >= m->rows)
+        if (m->d_block_pat && !m->d_hot_col && (int64_t)m->pat_blocks * 2 * kWave >= m->rows)
             for (int v : {16, 17, 18, 20, 21, 22})
                 if (n < max_out) out[n++] = v;
     } else if (m->format == SPMV_HIP_CSR_MERGE || m->format == SPMV_HIP_CSR_BAL) {
