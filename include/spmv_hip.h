@@ -17,7 +17,13 @@
  *   - Overwrite semantics for y in every format (the driver pre-fills y with
  *     garbage, driver_spmv.c:269), never writing past `rows`.
  *   - One host thread drives a handle; calls on one handle are ordered on the
- *     stream they are given.
+ *     stream they are given.  Products on ONE handle must not overlap (two
+ *     streams, or two host threads): merge-path / balanced handles keep their
+ *     tiles' carries in the handle, "hot_columns" handles a permuted copy of x
+ *     and partial results.  Different handles may run side by side.
+ *   - A handle belongs to the device that was current when it was created
+ *     (spmv_hip_init); every entry point that takes a handle makes that device
+ *     current for the call and restores the caller's device before it returns.
  */
 #ifndef SPMV_HIP_H
 #define SPMV_HIP_H
@@ -219,7 +225,10 @@ int spmv_hip_bench(spmv_hip_matrix *m, int min_iters, double min_seconds, double
                    int *iters, double *seconds);
 
 /* ---- vector helpers on device (driver_spmv.c:21-26, 301-302) ---------------- */
-/* *d_out (double, device) = ||d_x||_2 ; deterministic two-pass reduction */
+/* *d_out (double, device) = ||d_x||_2 ; deterministic two-pass reduction on the
+ * current device.  The partial sums live in library scratch kept per (device,
+ * stream): calls on different streams may overlap; the first call on a
+ * (device, stream) pair allocates its 8 KiB. */
 int spmv_hip_norm2_dev(int n, const void *d_x, int dtype, double *d_out, void *stream);
 /* d_x[i] = d_y[i] / *d_norm */
 int spmv_hip_scale_dev(int n, const void *d_y, void *d_x, int dtype, const double *d_norm, void *stream);
@@ -243,7 +252,15 @@ int spmv_hip_scale_dev(int n, const void *d_y, void *d_x, int dtype, const doubl
  *    from the plain product by reassociation (tolerance parity).  Costs
  *    (4 + V) bytes per entry plus (36 + 8 V) bytes per row of HBM; pays once x
  *    is far larger than the eight L2s together (R-MAT scale 26: 20.1 ms
- *    plain, 12.0 ms with 1, 9.7 ms with 2). */
+ *    plain, 12.0 ms with 1, 9.7 ms with 2).
+ *  "exact_order" = 1: spmv_hip_analyze may only pick kernel variants that leave
+ *    the bits of y as they are under the current setting, so that tuning noise
+ *    cannot change results from run to run: for the sliced formats the variants
+ *    that keep mult_csr_base's summation order (0, 16..23; a handle currently
+ *    on a reassociating variant 1..12 is put back on 0), for vector CSR the
+ *    current lanes per row and kernel family; lane-per-row CSR, merge-path and
+ *    balanced tiles give the same bits under every variant.  0 (default) lifts
+ *    the restriction. */
 int spmv_hip_set_option(spmv_hip_matrix *m, const char *name, int64_t value);
 /* sellcs_analyze_matrix (sell.c:30, sellcs_analyzer.c:46-120) re-thought for the
  * GPU: times every kernel variant of the handle's format `reps` times on a

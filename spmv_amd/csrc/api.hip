@@ -362,6 +362,8 @@ spmv_hip_matrix *spmv_hip_create_from_device_csr(int format, int rows, int colum
 int spmv_hip_mult_dev(spmv_hip_matrix *m, const void *d_x, void *d_y, void *stream)
 {
     if (!m) { set_error("NULL handle"); return 1; }
+    DeviceGuard on(m->device);
+    if (!on.ok) return 1;
     return launch_mult(m, d_x, d_y, (hipStream_t)stream);
 }
 
@@ -370,6 +372,8 @@ int spmv_hip_mult(spmv_hip_matrix *m, const double *x, double *y)
     clear_error();
     if (!m || !x || !y) { set_error("NULL argument"); return 1; }
     if (m->d_row_map) { set_error("row-mapped handles multiply through spmv_hip_mult_dev only"); return 1; }
+    DeviceGuard on(m->device);
+    if (!on.ok) return 1;
     if (ensure_vectors(m)) return 1;
     if (upload_vector(m, m->d_x, x, m->columns)) return 1;
     if (launch_mult(m, m->d_x, m->d_y, nullptr)) return 1;
@@ -387,6 +391,8 @@ int spmv_hip_mult_mv_dev(spmv_hip_matrix *m, int n, const void *d_x, int64_t ldx
         return 1;
     }
     if (n > 0 && (!d_x || !d_y) && m->rows > 0) { set_error("mult_mv: NULL vector block"); return 1; }
+    DeviceGuard on(m->device);
+    if (!on.ok) return 1;
     return launch_mult_mv(m, n, d_x, ldx, d_y, ldy, (hipStream_t)stream);
 }
 
@@ -397,6 +403,8 @@ int spmv_hip_mult_mv(spmv_hip_matrix *m, int n, const double *x, double *y)
     if (n < 0) { set_error("mult_mv: negative vector count %d", n); return 1; }
     if (m->d_row_map) { set_error("row-mapped handles multiply through spmv_hip_mult_mv_dev only"); return 1; }
     if (n == 0) return 0;
+    DeviceGuard on(m->device);
+    if (!on.ok) return 1;
     const size_t es = dtype_size(m->dtype);
     const size_t nx = (size_t)n * (size_t)m->columns, ny = (size_t)n * (size_t)m->rows;
     char *dx = nullptr, *dy = nullptr;
@@ -423,6 +431,7 @@ int spmv_hip_mult_mv(spmv_hip_matrix *m, int n, const double *x, double *y)
 int spmv_hip_free(spmv_hip_matrix *m)
 {
     if (!m) return 0;
+    DeviceGuard on(m->device);            // a failed switch still frees: hipFree takes pointers of any device
     release_csr(m);
     void *ptrs[] = {m->d_tile_coord, m->d_row_carry, m->d_val_carry, m->d_nzr_id, m->d_nzr_end, m->d_slice_ptr,
                     m->d_row_order, m->d_slice_ident, m->d_scol, m->d_sval, m->d_sorted_len, m->d_vop_ptr, m->d_vop_len,
@@ -440,6 +449,8 @@ int spmv_hip_bench(spmv_hip_matrix *m, int min_iters, double min_seconds, double
     if (!m || !x || !iters || !seconds) { set_error("NULL argument"); return 1; }
     if (m->rows != m->columns) { set_error("bench: matrix is not square"); return 1; }
     if (m->d_row_map) { set_error("row-mapped handles multiply through spmv_hip_mult_dev only"); return 1; }
+    DeviceGuard on(m->device);
+    if (!on.ok) return 1;
     if (ensure_vectors(m)) return 1;
     if (upload_vector(m, m->d_x, x, m->columns)) return 1;
     hipEvent_t e0, e1;
@@ -537,7 +548,16 @@ int spmv_hip_set_option(spmv_hip_matrix *m, const char *name, int64_t value)
 {
     clear_error();
     if (!m || !name) { set_error("NULL argument"); return 1; }
+    DeviceGuard on(m->device);
+    if (!on.ok) return 1;
     if (!strcmp(name, "variant")) { m->variant = (int)value; return 0; }
+    if (!strcmp(name, "exact_order")) {
+        m->exact_order = value != 0;
+        // sliced formats: leave the reassociating 16-byte-load variants for the exact-order kernel
+        const bool sliced64 = m->d_slice_ptr && m->slice_height == kWave && m->format != SPMV_HIP_SELL_DFC;
+        if (m->exact_order && sliced64 && m->variant >= 1 && m->variant <= 12) m->variant = 0;
+        return 0;
+    }
     if (!strcmp(name, "hot_columns")) {
         if (value == 0) { drop_hot_columns(m); return 0; }
         if (value != 1 && value != 2) { set_error("hot_columns takes 0, 1 or 2"); return 1; }
@@ -598,6 +618,18 @@ static int analyze_impl(spmv_hip_matrix *m, int reps, float *best_ms_out)
     const int keep = vec ? m->lanes_per_row + 256 * m->variant : m->variant;
     int best = keep, rc = 0;
     float best_ms = 0;
+    if (m->exact_order && !m->xcd_sub) {                    // keep only the candidates that leave y's bits alone
+        int kept = 0;
+        for (int i = 0; i < n; i++)
+            if (candidate_keeps_bits(m, cand[i])) cand[kept++] = cand[i];
+        n = kept;
+        if (n == 0 || (n == 1 && cand[0] == keep && !best_ms_out)) {
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            return 0;
+        }
+    }
+    bool first = true;
     for (int i = 0; i < n && !rc; i++) {
         apply(cand[i]);
         if (launch_mult(m, m->d_x, m->d_y, nullptr)) { rc = 1; break; }          // warm-up
@@ -609,7 +641,7 @@ static int analyze_impl(spmv_hip_matrix *m, int reps, float *best_ms_out)
             if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = 1; break; }
             total += ms;
         }
-        if (!rc && (i == 0 || total < best_ms)) { best_ms = total; best = cand[i]; }
+        if (!rc && (first || total < best_ms)) { best_ms = total; best = cand[i]; first = false; }
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -623,6 +655,8 @@ int spmv_hip_analyze(spmv_hip_matrix *m, int reps)
 {
     clear_error();
     if (!m) { set_error("NULL handle"); return 1; }
+    DeviceGuard on(m->device);
+    if (!on.ok) return 1;
     return analyze_impl(m, reps, nullptr);
 }
 
@@ -775,6 +809,8 @@ int spmv_hip_download(const spmv_hip_matrix *m, int which, void *host, size_t by
     if (!src) { set_error("array %d is not part of format %d", which, m->format); return 1; }
     if (bytes != need) { set_error("array %d holds %zu bytes, caller passed %zu", which, need, bytes); return 1; }
     if (need == 0) return 0;
+    DeviceGuard on(m->device);
+    if (!on.ok) return 1;
     SPMV_HIP_TRY(hipMemcpy(host, src, need, hipMemcpyDeviceToHost), return 1);
     return 0;
 }

@@ -629,11 +629,15 @@ int build_block_patterns(spmv_hip_matrix *m, hipStream_t st)
 // column is described by the single number d, so a kernel that knows it need not read the 64 column
 // indices.  diag[first column of slice s + j] = d, or INT_MIN when the column is not diagonal;
 // *ndiag counts the diagonal ones.  One wave per slice; padding lanes (j >= length of their row) are
-// free.
+// free.  A column with a real entry whose value is zero gets no descriptor: the product kernels
+// recognise padding lanes of described columns by their zero value (they take x[0] there, as the
+// reference's (column 0, value 0) padding does).
+template <typename T>
 __global__ __launch_bounds__(kWave) void slice_diag_kernel(int rows, int nslices, const int *__restrict__ row_ptr,
                                                            const int *__restrict__ row_order,
                                                            const int64_t *__restrict__ slice_ptr,
-                                                           const int *__restrict__ scol, int *__restrict__ diag,
+                                                           const int *__restrict__ scol, const T *__restrict__ sval,
+                                                           int *__restrict__ diag,
                                                            unsigned long long *__restrict__ ndiag)
 {
     const int s = blockIdx.x, lane = threadIdx.x;
@@ -647,11 +651,12 @@ __global__ __launch_bounds__(kWave) void slice_diag_kernel(int rows, int nslices
     for (int j = 0; j < width; j++) {
         const bool real = j < len;
         const int d = real ? scol[base + (int64_t)j * kWave + lane] - row : 0;
+        const bool zero = real && sval[base + (int64_t)j * kWave + lane] == (T)0;
         const unsigned long long mask = __ballot(real);
         int out = 0;                                           // a column of padding only: any distance will do
         if (mask) {
             const int d0 = __builtin_amdgcn_readlane(d, __builtin_ctzll(mask));
-            out = __ballot(real && d != d0) ? INT_MIN : d0;
+            out = __ballot((real && d != d0) || zero) ? INT_MIN : d0;
         }
         if (lane == 0) diag[(base >> 6) + j] = out;
         found += out != INT_MIN;
@@ -752,8 +757,14 @@ int build_sliced(spmv_hip_matrix *m, const int *d_row_ptr, const int *d_col, con
             if (dev_alloc<unsigned long long>(nullptr, &d_count, 1)) break;
             bool ok = hipMemsetAsync(d_count, 0, sizeof count, st) == hipSuccess;
             if (ok) {
-                hipLaunchKernelGGL(slice_diag_kernel, dim3((unsigned)m->nslices), dim3(kWave), 0, st, rows, m->nslices,
-                                   d_row_ptr, m->d_row_order, m->d_slice_ptr, m->d_scol, m->d_sdiag, d_count);
+                if (m->dtype == SPMV_HIP_F32)
+                    hipLaunchKernelGGL(slice_diag_kernel<float>, dim3((unsigned)m->nslices), dim3(kWave), 0, st, rows,
+                                       m->nslices, d_row_ptr, m->d_row_order, m->d_slice_ptr, m->d_scol,
+                                       (const float *)m->d_sval, m->d_sdiag, d_count);
+                else
+                    hipLaunchKernelGGL(slice_diag_kernel<double>, dim3((unsigned)m->nslices), dim3(kWave), 0, st, rows,
+                                       m->nslices, d_row_ptr, m->d_row_order, m->d_slice_ptr, m->d_scol,
+                                       (const double *)m->d_sval, m->d_sdiag, d_count);
                 ok = hipGetLastError() == hipSuccess &&
                      hipMemcpyAsync(&count, d_count, sizeof count, hipMemcpyDeviceToHost, st) == hipSuccess &&
                      hipStreamSynchronize(st) == hipSuccess;

@@ -6,8 +6,14 @@
  *     build/spmv_hip MODE LIST OUT.csv
  *
  * MODE is one of the reference's mode strings (driver_spmv.c:186-261) -- each
- * selects the same storage format, now resident in HBM -- optionally suffixed
- * with ":f32" for float storage/accumulation.  Per matrix of LIST the driver
+ * selects the same storage format, now resident in HBM -- optionally followed by
+ * ":"-separated suffixes: "f32" / "f64" (storage and accumulation type) and, for
+ * sell / sell_dfc, a number = the sorting window sigma ("sell:1024", "sell:1024:f32").
+ * The reference keeps sigma and C in two globals (sell.c:4-5: 16384 and 64); without
+ * a suffix the environment variable SPMV_SIGMA is consulted, then that default.
+ * SPMV_EXACT_ORDER=0 lets the kernel trial also pick variants that reassociate the
+ * row sums (default: only variants whose y has the same bits run to run).
+ * Per matrix of LIST the driver
  *   1. estimates the memory need like enought_memory (driver_spmv.c:50-110;
  *      .bin headers are read as binary here -- the reference parses them as text),
  *   2. loads it (.mtx: spmv_hip_load_mtx; .bin: spmv_hip_load_bin, the reference's
@@ -110,7 +116,8 @@ static void coo_to_csr(int rows, int nnz, const struct mtx *coo, int **rp, int *
 }
 
 /* MODE -> handle: the if/else chain of driver_spmv.c:186-261 */
-static spmv_hip_matrix *create_for_mode(const char *mode, int rows, int cols, int nnz, struct mtx *coo, int dtype)
+static spmv_hip_matrix *create_for_mode(const char *mode, int rows, int cols, int nnz, struct mtx *coo, int dtype,
+                                        long sigma)
 {
     /* "coo" (driver_spmv.c:186-188): create_coo sorts by (row, col) and mult_coo (coo.c:3-14) sums each
      * row's entries in that order from 0.0 -- the sums of mult_csr_base, so it runs on the lane-per-row
@@ -128,8 +135,8 @@ static spmv_hip_matrix *create_for_mode(const char *mode, int rows, int cols, in
         int *rp, *cj; double *va;
         spmv_hip_sort_coo(nnz, coo);                       /* create_csr's side effect (csr.c:167) */
         coo_to_csr(rows, nnz, coo, &rp, &cj, &va);
-        spmv_hip_matrix *m = !strcmp(mode, "sell")       ? spmv_hip_create_sell(rows, cols, nnz, rp, cj, va, dtype, 0, 0)
-                             : !strcmp(mode, "sell_dfc") ? spmv_hip_create_sell_dfc(rows, cols, nnz, rp, cj, va, dtype, 0, 0)
+        spmv_hip_matrix *m = !strcmp(mode, "sell")       ? spmv_hip_create_sell(rows, cols, nnz, rp, cj, va, dtype, 0, sigma)
+                             : !strcmp(mode, "sell_dfc") ? spmv_hip_create_sell_dfc(rows, cols, nnz, rp, cj, va, dtype, 0, sigma)
                                                          : spmv_hip_create_sellp(rows, cols, nnz, rp, cj, va, dtype, 0);
         free(rp); free(cj); free(va);
         return m;
@@ -141,18 +148,28 @@ static spmv_hip_matrix *create_for_mode(const char *mode, int rows, int cols, in
 int main(int argc, char *argv[])
 {
     if (argc != 4) {
-        printf("Usage: spmv_hip [coo|csr_base|csr_vec|csr_merge|csr_bal|sellp_vec|ell|sell|sell_dfc|auto][:f32] <mtx list> <output csv>\n");
+        printf("Usage: spmv_hip [coo|csr_base|csr_vec|csr_merge|csr_bal|sellp_vec|ell|sell|sell_dfc|auto][:sigma][:f32] <mtx list> <output csv>\n");
         exit(-1);
     }
     char mode[64];
     snprintf(mode, sizeof mode, "%s", argv[1]);
     int dtype = SPMV_HIP_F64;
+    long sigma = getenv("SPMV_SIGMA") ? atol(getenv("SPMV_SIGMA")) : 0;       /* 0 = the reference's 16384 (sell.c:4) */
     char *colon = strchr(mode, ':');
-    if (colon) {
-        if (!strcmp(colon, ":f32")) dtype = SPMV_HIP_F32;
-        else if (strcmp(colon, ":f64")) { printf("Error: Unknown execution mode.\n"); exit(-1); }
-        *colon = 0;
+    if (colon) *colon++ = 0;
+    while (colon && *colon) {                                                /* suffixes: f32 | f64 | <sigma> */
+        char *next = strchr(colon, ':');
+        if (next) *next++ = 0;
+        char *end;
+        long number = strtol(colon, &end, 10);
+        if (!strcmp(colon, "f32")) dtype = SPMV_HIP_F32;
+        else if (!strcmp(colon, "f64")) dtype = SPMV_HIP_F64;
+        else if (end != colon && !*end && number > 0 && (!strcmp(mode, "sell") || !strcmp(mode, "sell_dfc"))) sigma = number;
+        else { printf("Error: Unknown execution mode.\n"); exit(-1); }
+        colon = next;
     }
+    const char *exact_env = getenv("SPMV_EXACT_ORDER");
+    const int exact_order = exact_env ? atoi(exact_env) != 0 : 1;
     const int vbytes = dtype == SPMV_HIP_F32 ? 4 : 8;
     FILE *infd = fopen(argv[2], "r");
     if (!infd) { perror("Error openning file input for matrix list.\n"); exit(-1); }
@@ -187,8 +204,9 @@ int main(int argc, char *argv[])
         else { printf("Unkown file extension\n"); return 1; }
         if (rows != columns) { printf("Matrix is not square\n"); return 1; }
 
-        spmv_hip_matrix *m = create_for_mode(mode, rows, columns, nnz, coo, dtype);
+        spmv_hip_matrix *m = create_for_mode(mode, rows, columns, nnz, coo, dtype, sigma);
         if (!m) die("create");
+        if (spmv_hip_set_option(m, "exact_order", exact_order)) die("set_option");
         if (spmv_hip_analyze(m, 3)) die("analyze");
 
         double *x = (double *)malloc(sizeof(double) * (size_t)columns);

@@ -30,6 +30,26 @@ void clear_error();
 
 inline size_t dtype_size(int dtype) { return dtype == SPMV_HIP_F32 ? 4 : 8; }
 
+// Makes `device` current for the scope of an entry point and restores the caller's device after:
+// a handle's arrays live on the device it was created on, whatever device the calling thread has
+// selected since.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false, ok = true;
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; set_error("no HIP device available"); return; }
+        if (prev != device) {
+            ok = hipSetDevice(device) == hipSuccess;
+            switched = ok;
+            if (!ok) set_error("hipSetDevice(%d) failed", device);
+        }
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 } // namespace spmv
 
 // The opaque handle of the C ABI.
@@ -50,6 +70,7 @@ struct spmv_hip_matrix {
                                           // rows repeat one pattern of distances from the diagonal, else 0
     int pat_blocks = 0;            // how many blocks do
     int variant = 0;               // kernel variant inside the format (spmv_hip_set_option "variant")
+    bool exact_order = false;      // spmv_hip_analyze may only pick variants that leave y's bits as they are
     double max_padding = 0;        // > 0: building a sliced layout fails when stored > max_padding * nnz
 
     // merge-path / balanced tiles
@@ -111,6 +132,7 @@ int launch_mult(const spmv_hip_matrix *m, const void *d_x, void *d_y, hipStream_
 int launch_mult_mv(const spmv_hip_matrix *m, int n, const void *d_x, int64_t ldx, void *d_y, int64_t ldy,
                    hipStream_t stream);
 int variant_candidates(const spmv_hip_matrix *m, int *out, int max_out);
+bool candidate_keeps_bits(const spmv_hip_matrix *m, int candidate);
 int launch_norm2(int n, const void *d_x, int dtype, double *d_out, hipStream_t stream);
 int launch_scale(int n, const void *d_y, void *d_x, int dtype, const double *d_norm, hipStream_t stream);
 

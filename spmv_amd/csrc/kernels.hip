@@ -23,8 +23,11 @@
 #include "device_utils.h"
 
 #include <algorithm>
-#include <type_traits>
 #include <climits>
+#include <map>
+#include <mutex>
+#include <type_traits>
+#include <utility>
 
 namespace spmv {
 
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(kBlock) void sliced64_kernel(int rows, int nslices,
 // rows; the P partial sums of a row are then added across the lane groups, so
 // the in-row order differs from mult_csr_base (parity by tolerance, not bits).
 // Columns past the slice width are read from the last column (no extra HBM
-// traffic) and multiplied by zero.
+// traffic) and left out of the sums.
 template <typename T, bool PERM, int U, bool NT>
 __global__ __launch_bounds__(kBlock) void sliced64_wide_kernel(int rows, int nslices,
                                                                const int64_t *__restrict__ slice_ptr,
@@ -486,7 +489,10 @@ __global__ __launch_bounds__(kBlock) void sliced64_wide_kernel(int rows, int nsl
         for (int u = 0; u < U; u++) {
             const bool live = P * (jj + u) + h < width;
 #pragma unroll
-            for (int k = 0; k < R; k++) acc[k] = fma_t(x[cc[u][k]], live ? vv[u][k] : (T)0, acc[k]);
+            for (int k = 0; k < R; k++) {
+                const T xv = x[cc[u][k]];
+                if (live) acc[k] = fma_t(xv, vv[u][k], acc[k]);    // no 0 * x here: x may be non-finite
+            }
         }
     }
     // add the P column groups, then hand row l to lane l for one coalesced store
@@ -509,8 +515,12 @@ __global__ __launch_bounds__(kBlock) void sliced64_wide_kernel(int rows, int nsl
 // read: lane k gathers x[row_k + d] (padding lanes carry value 0 and clamp the address into x).  A
 // 27-point stencil, a band or a block-diagonal matrix then streams 8 (fp64) instead of 12 bytes per
 // entry.  The descriptor is wave-uniform, so the choice is a scalar branch.  One fma per column in
-// ascending column order: bit-identical to sliced64_kernel and mult_csr_base (csr.c:4-13) for
-// finite x.
+// ascending column order: bit-identical to sliced64_kernel and mult_csr_base (csr.c:4-13).
+// A padding entry is stored as (column 0, value 0) (sellcs_format.c:167,171, sellp.c:440-452), so
+// the reference multiplies x[0] by 0 there -- which is NaN for a non-finite x[0].  The build pass
+// gives a descriptor only to columns whose real entries all have a non-zero value; in such a column
+// a zero value marks a padding lane, and that lane takes x[0] as its operand, so y carries the
+// reference's bits for non-finite x too.
 template <typename T, bool PERM, int U, bool NT>
 __global__ __launch_bounds__(kBlock) void sliced64_diag_kernel(int rows, int cols, int nslices,
                                                                const int64_t *__restrict__ slice_ptr,
@@ -532,26 +542,29 @@ __global__ __launch_bounds__(kBlock) void sliced64_diag_kernel(int rows, int col
     const T *v = sval + base + lane;
     const int *c = scol + base + lane;
     const int *dg = sdiag + (base >> 6);
-    const int last = cols - 1;
+    const int last = max(cols - 1, 0);
+    const T x0 = width > 0 ? x[0] : (T)0;           // a slice has entries only when the matrix has columns
     T acc = 0;
     int j = 0;
     // B columns at once: value loads, descriptors / index loads, gathers, then the fmas in column order
     auto batch = [&](auto bsize) {
         constexpr int B = decltype(bsize)::value;
         int cc[B];
+        bool dia[B];
         T vv[B], xx[B];
 #pragma unroll
         for (int u = 0; u < B; u++) vv[u] = NT ? __builtin_nontemporal_load(v + (int64_t)(j + u) * kWave) : v[(int64_t)(j + u) * kWave];
 #pragma unroll
         for (int u = 0; u < B; u++) {
             const int d = __builtin_amdgcn_readfirstlane(dg[j + u]);
-            if (d != INT_MIN) cc[u] = min(max(row + d, 0), last);
+            dia[u] = d != INT_MIN;
+            if (dia[u]) cc[u] = min(max(row + d, 0), last);
             else cc[u] = NT ? __builtin_nontemporal_load(c + (int64_t)(j + u) * kWave) : c[(int64_t)(j + u) * kWave];
         }
 #pragma unroll
         for (int u = 0; u < B; u++) xx[u] = x[cc[u]];
 #pragma unroll
-        for (int u = 0; u < B; u++) acc = fma_t(xx[u], vv[u], acc);
+        for (int u = 0; u < B; u++) acc = fma_t(dia[u] && vv[u] == (T)0 ? x0 : xx[u], vv[u], acc);
         j += B;
     };
     while (j + U <= width) batch(std::integral_constant<int, U>());
@@ -1081,6 +1094,27 @@ int variant_candidates(const spmv_hip_matrix *m, int *out, int max_out)
     return n;
 }
 
+// Whether `candidate` (as listed by variant_candidates) gives y the same bits as the handle's
+// current setting -- what spmv_hip_analyze may choose from under the option "exact_order".
+//   sliced formats of height 64: 0 and 16..23 keep the order of mult_csr_base; 1..12 reassociate.
+//   padding-free SELL, lane-per-row CSR, merge-path / balanced tiles: every variant sums alike.
+//   vector CSR: the bits depend on the lanes per row and on the kernel family (direct loads, one
+//     fma per entry: variants 0..4; products staged in LDS, then added: 5..8).
+bool candidate_keeps_bits(const spmv_hip_matrix *m, int candidate)
+{
+    const bool sliced64 = m->d_slice_ptr && m->slice_height == kWave && m->format != SPMV_HIP_SELL_DFC;
+    if (sliced64) {
+        const bool now_exact = m->variant == 0 || m->variant >= 16;
+        const bool cand_exact = candidate == 0 || candidate >= 16;
+        return now_exact ? cand_exact : candidate == m->variant;
+    }
+    if (m->format == SPMV_HIP_CSR_VECTOR) {
+        const int g = candidate & 255, v = candidate >> 8;
+        return g == m->lanes_per_row && (v >= 5) == (m->variant >= 5);
+    }
+    return true;
+}
+
 template <typename T, bool PERM>
 static int launch_sliced64(const spmv_hip_matrix *m, const T *x, T *y, hipStream_t st)
 {
@@ -1372,21 +1406,25 @@ int launch_mult(const spmv_hip_matrix *m, const void *d_x, void *d_y, hipStream_
     return launch_mult_t<double>(m, (const double *)d_x, (double *)d_y, stream);
 }
 
-// per-device scratch for the two-pass norm (kNormBlocks doubles), allocated on first use
-static double *norm_scratch()
+// Scratch of the two-pass norm: kNormBlocks partial sums.  Launches that may run side by side must
+// not share it, so each (device, stream) pair gets its own, allocated on that pair's first call and
+// kept until the process ends (8 KiB each).
+static double *norm_scratch(hipStream_t st)
 {
-    static double *scratch[64] = {nullptr};
+    static std::mutex lock;
+    static std::map<std::pair<int, hipStream_t>, double *> scratch_of;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (!scratch[dev] && hipMalloc((void **)&scratch[dev], kNormBlocks * sizeof(double)) != hipSuccess)
-        scratch[dev] = nullptr;
-    return scratch[dev];
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> hold(lock);
+    double *&p = scratch_of[std::make_pair(dev, st)];
+    if (!p && hipMalloc((void **)&p, kNormBlocks * sizeof(double)) != hipSuccess) p = nullptr;
+    return p;
 }
 
-int launch_norm2(int n, const void *d_x, int dtype, double *d_out, hipStream_t st)
+static int launch_norm2_with(double *partial, int n, const void *d_x, int dtype, double *d_out, hipStream_t st)
 {
-    double *partial = norm_scratch();
-    if (!partial) { set_error("norm2: could not allocate scratch"); return 1; }
+    // every launch writes partial[0..blocks) before the second kernel reads exactly that range, so
+    // whatever an earlier, larger call left behind is never read
     int blocks = (int)std::min<int64_t>(kNormBlocks, cdiv(std::max(n, 1), kBlock));
     if (dtype == SPMV_HIP_F32)
         hipLaunchKernelGGL((sumsq_partial_kernel<float>), dim3(blocks), dim3(kBlock), 0, st, n, (const float *)d_x, partial);
@@ -1395,6 +1433,13 @@ int launch_norm2(int n, const void *d_x, int dtype, double *d_out, hipStream_t s
     hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(kBlock), 0, st, blocks, partial, d_out);
     SPMV_HIP_TRY(hipGetLastError(), return 1);
     return 0;
+}
+
+int launch_norm2(int n, const void *d_x, int dtype, double *d_out, hipStream_t st)
+{
+    double *partial = norm_scratch(st);
+    if (!partial) { set_error("norm2: could not allocate scratch"); return 1; }
+    return launch_norm2_with(partial, n, d_x, dtype, d_out, st);
 }
 
 int launch_scale(int n, const void *d_y, void *d_x, int dtype, const double *d_norm, hipStream_t st)

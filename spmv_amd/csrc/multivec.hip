@@ -49,23 +49,31 @@ __global__ __launch_bounds__(kBlock) void sliced64_mv_kernel(int rows, int cols,
     const int r = s * kWave + lane;
     const int row = r < rows ? (PERM && !slice_ident[s] ? row_order[r] : r) : 0;
     const int *dg = sdiag ? sdiag + (base >> 6) : nullptr;
-    const int last = cols - 1;
-    // the index of entry j of this lane's row: computed for a diagonal column, loaded otherwise
-    auto column = [&](int jj) {
+    const int last = max(cols - 1, 0);
+    // the index of entry j of this lane's row: computed for a diagonal column, loaded otherwise.  In a
+    // diagonal column a zero value marks a padding lane (the build pass describes no column that
+    // holds a real zero); padding is stored as (column 0, value 0) (sellcs_format.c:167,171), so that
+    // lane's operand is x_v[0] -- what the reference multiplies by zero
+    auto column = [&](int jj, bool &diagonal) {
         const int d = dg ? __builtin_amdgcn_readfirstlane(dg[jj]) : INT_MIN;
-        return d != INT_MIN ? min(max(row + d, 0), last) : stream_load<int, NT>(c + (int64_t)jj * kWave);
+        diagonal = d != INT_MIN;
+        return diagonal ? min(max(row + d, 0), last) : stream_load<int, NT>(c + (int64_t)jj * kWave);
     };
-    T acc[NV];
+    T acc[NV], x0[NV];
 #pragma unroll
-    for (int k = 0; k < NV; k++) acc[k] = 0;
+    for (int k = 0; k < NV; k++) {
+        acc[k] = 0;
+        x0[k] = dg && width > 0 ? x[k * ldx] : (T)0;
+    }
     int j = 0;
     for (; j + U <= width; j += U) {
         int cc[U];
+        bool dia[U];
         T vv[U], xx[NV][U];
 #pragma unroll
         for (int u = 0; u < U; u++) vv[u] = stream_load<T, NT>(v + (int64_t)(j + u) * kWave);
 #pragma unroll
-        for (int u = 0; u < U; u++) cc[u] = column(j + u);
+        for (int u = 0; u < U; u++) cc[u] = column(j + u, dia[u]);
 #pragma unroll
         for (int k = 0; k < NV; k++)
 #pragma unroll
@@ -73,13 +81,14 @@ __global__ __launch_bounds__(kBlock) void sliced64_mv_kernel(int rows, int cols,
 #pragma unroll
         for (int k = 0; k < NV; k++)
 #pragma unroll
-            for (int u = 0; u < U; u++) acc[k] = fma_t(xx[k][u], vv[u], acc[k]);
+            for (int u = 0; u < U; u++) acc[k] = fma_t(dia[u] && vv[u] == (T)0 ? x0[k] : xx[k][u], vv[u], acc[k]);
     }
     for (; j < width; j++) {
-        const int cc = column(j);
+        bool dia;
+        const int cc = column(j, dia);
         const T vv = stream_load<T, NT>(v + (int64_t)j * kWave);
 #pragma unroll
-        for (int k = 0; k < NV; k++) acc[k] = fma_t(x[k * ldx + cc], vv, acc[k]);
+        for (int k = 0; k < NV; k++) acc[k] = fma_t(dia && vv == (T)0 ? x0[k] : x[k * ldx + cc], vv, acc[k]);
     }
     if (r < rows) {
 #pragma unroll

@@ -81,3 +81,70 @@ def test_two_ranks_on_one_gpu(orc, exchange, fmt_name):
         got[r0:r0 + len(y)] = y
     assert not np.isnan(got).any()
     assert orc.rel_l2(got, want) <= 1e-13
+
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _run_bench(extra_env, *argv, timeout=400):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SPMV_BENCH_BACKEND")}
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_bench_launches_its_own_ranks_gloo_rehearsal():
+    """`python bench.py --gpus 2` by itself: two ranks on this box's one GPU over gloo, one valid line."""
+    import json
+    p = _run_bench({"SPMV_BENCH_BACKEND": "gloo"}, "--gpus", "2", "--size", "96", "--steps", "5", "--warmup", "2")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 5 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["config"]["rows"] == 2 * 96 ** 3
+    comm = rec["communication"]                      # on by default for N > 1
+    assert comm["halo_entries_rank0"] == 96 * 96 and comm["exchange_alone_ms"] > 0 and "exposed_ms" in comm
+
+
+def test_bench_refuses_more_rccl_ranks_than_gpus():
+    have = torch.cuda.device_count()
+    p = _run_bench({}, "--gpus", str(have + 1), "--steps", "2")
+    assert p.returncode != 0 and p.stdout.strip() == ""
+    assert f"has {have}" in p.stderr
+
+
+def _rccl_world1(port, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", device_id=dev)
+    try:
+        a = torch.arange(1000, dtype=torch.float64, device=dev)
+        full = torch.empty(1000, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(full, a)
+        s = torch.sum(a * a).reshape(1)
+        dist.all_reduce(s)
+        recv = torch.zeros(64, dtype=torch.float64, device=dev)
+        ops = [dist.P2POp(dist.isend, a[100:164].contiguous(), 0), dist.P2POp(dist.irecv, recv, 0)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        torch.cuda.synchronize()
+        out_q.put((bool(torch.equal(full, a)), float(s), bool(torch.equal(recv, a[100:164]))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_collectives_of_the_row_block_product_run_on_this_gpu():
+    """The three RCCL calls of spmv_amd.distributed (all_gather_into_tensor, all_reduce, one group of
+    isend/irecv on device tensors) on a one-rank communicator: what one GPU can run of the RCCL path."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1, args=(_free_port(), q))
+    p.start()
+    gathered, sumsq, p2p = q.get(timeout=110)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert gathered and p2p and sumsq == float(sum(i * i for i in range(1000)))
