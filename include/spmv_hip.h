@@ -213,6 +213,85 @@ int spmv_hip_mult_mv_dev(spmv_hip_matrix *m, int n, const void *d_x, int64_t ldx
  * counterpart (the reference has no partitioned product). */
 int spmv_hip_set_row_map(spmv_hip_matrix *m, const int *d_row_map);
 
+/* ---- row-block partitioned product over several GPUs ----------------------------
+ * The reference has no partitioned product; its one precedent is the equal-nnz
+ * contiguous chunking of create_csr_bal (csr_bal.c:83-85), applied here to whole
+ * rows.  A block of a square matrix owns rows [row_begin, row_begin + rows) and the
+ * same range of x and y.  Its rows whose columns all lie in that range ("interior")
+ * are multiplied by a matrix in the caller's format against the local part of x;
+ * the others ("boundary", a compact CSR with a row map: lane-per-row beside the
+ * formats that keep mult_csr_base's summation order, vector CSR otherwise) against
+ * [x_local | halo], the halo being the x entries of the block's remote columns in
+ * ascending global column order.  Every row is still summed whole by one kernel,
+ * so with "exact_order" set on a lane-per-row or sliced format the partitioned
+ * product has the bits of mult_csr_base (csr.c:4-13). */
+typedef struct spmv_hip_rowblock spmv_hip_rowblock;
+typedef struct spmv_hip_dist spmv_hip_dist;
+
+typedef struct spmv_hip_rowblock_info {
+    int     format, dtype, device;
+    int     rows, row_begin, columns_global;
+    int64_t nnz, interior_nnz, boundary_nnz;
+    int     boundary_rows;       /* rows with at least one remote column                      */
+    int     halo;                /* distinct remote columns                                    */
+    int     send;                /* entries of the send list (spmv_hip_rowblock_set_send_list) */
+    int64_t interior_stored;     /* entries the interior matrix holds in HBM incl. padding     */
+    int     interior_variant, boundary_lanes_per_row, boundary_variant;
+    int64_t device_bytes;
+} spmv_hip_rowblock_info;
+
+/* bounds[0..parts]: contiguous row blocks with about nnz/parts non-zeros each --
+ * block p ends at the first row whose row_ptr reaches (p+1)*nnz/parts (the share
+ * rule of csr_bal.c:83-85 on rows) moved to the nearest multiple of `snap` rows
+ * (1024 keeps SELL sorting windows and slices inside one block).  Host arrays. */
+int spmv_hip_partition_rows(int rows, const int *row_ptr, int parts, int snap, int *bounds);
+
+/* Builds a block on the current device from its CSR in HBM (row pointers local to
+ * the block, GLOBAL column indices, dtype values); the arrays are only read.
+ * format / p0 / p1 as for spmv_hip_create_from_device_csr (the interior matrix). */
+spmv_hip_rowblock *spmv_hip_rowblock_create(int format, int rows, int row_begin, int columns_global, int64_t nnz,
+                                            const int *d_row_ptr, const int *d_col, const void *d_val, int dtype,
+                                            int64_t p0, int64_t p1, void *stream);
+int spmv_hip_rowblock_free(spmv_hip_rowblock *rb);
+int spmv_hip_rowblock_get_info(const spmv_hip_rowblock *rb, spmv_hip_rowblock_info *info);
+/* "exact_order" as for spmv_hip_set_option, applied to the interior matrix (the
+ * kernel trial is repeated under the restriction) */
+int spmv_hip_rowblock_set_option(spmv_hip_rowblock *rb, const char *name, int64_t value);
+/* columns[0..halo): the remote columns, ascending (host array) */
+int spmv_hip_rowblock_halo_columns(const spmv_hip_rowblock *rb, int *columns);
+/* The local x entries (indices into x_local) other blocks need from this one, in
+ * the order they are sent; spmv_hip_rowblock_pack gathers them:
+ * d_send[k] = d_x[local_index[k]]. */
+int spmv_hip_rowblock_set_send_list(spmv_hip_rowblock *rb, int count, const int *local_index);
+int spmv_hip_rowblock_pack(spmv_hip_rowblock *rb, const void *d_x, void *d_send, void *stream);
+/* y[0..rows) = interior rows * d_x[0..rows); boundary rows receive 0 here and their
+ * value from mult_boundary, which must follow on the same stream once
+ * d_x_ext[rows..rows+halo) holds the halo. */
+int spmv_hip_rowblock_mult_interior(spmv_hip_rowblock *rb, const void *d_x, void *d_y, void *stream);
+int spmv_hip_rowblock_mult_boundary(spmv_hip_rowblock *rb, const void *d_x_ext, void *d_y, void *stream);
+
+/* All blocks driven by ONE host thread (reference threading model: the driver is
+ * single-threaded, driver_spmv.c:112-347): the matrix is cut with
+ * spmv_hip_partition_rows into `ngpus` blocks, block p built on devices[p]
+ * (NULL = devices 0..ngpus-1; a device may be named more than once), each with a
+ * compute and a communication stream.  One product packs the halo entries on every
+ * block, pushes them to their consumers with peer-to-peer copies (xGMI) on the
+ * communication streams while the interior products run, then multiplies the
+ * boundary rows.  Sorts the caller's coo in place like the other creators. */
+spmv_hip_dist *spmv_hip_dist_create(int format, int rows, int columns, int nnz, struct mtx *coo, int dtype, int64_t p0,
+                                    int64_t p1, int ngpus, const int *devices);
+/* mult_X with host vectors (driver_spmv.c:276) */
+int spmv_hip_dist_mult(spmv_hip_dist *d, const double *x, double *y);
+/* the timed power loop (driver_spmv.c:292-308) over all blocks: exchange + products
+ * timed on the host clock from the first launch to the last block's completion,
+ * x = y / ||y||_2 (norm over all blocks) untimed */
+int spmv_hip_dist_bench(spmv_hip_dist *d, int min_iters, double min_seconds, double *x, int *iters, double *seconds);
+/* spmv_hip_rowblock_set_option on every block */
+int spmv_hip_dist_set_option(spmv_hip_dist *d, const char *name, int64_t value);
+/* ngpus, bounds[0..ngpus], blocks[0..ngpus) -- any of them may be NULL */
+int spmv_hip_dist_get_info(const spmv_hip_dist *d, int *ngpus, int *bounds, spmv_hip_rowblock_info *blocks);
+int spmv_hip_dist_free(spmv_hip_dist *d);
+
 /* free_X (csr.c:205-210, sellp.c:461-465; the reference leaks the others) */
 int spmv_hip_free(spmv_hip_matrix *m);
 

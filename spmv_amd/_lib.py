@@ -28,6 +28,14 @@ class Info(C.Structure):
                 ("variant", C.c_int), ("hot_columns", C.c_int), ("diag_columns", C.c_int64), ("pattern_blocks", C.c_int)]
 
 
+class RowBlockInfo(C.Structure):
+    _fields_ = [("format", C.c_int), ("dtype", C.c_int), ("device", C.c_int), ("rows", C.c_int), ("row_begin", C.c_int),
+                ("columns_global", C.c_int), ("nnz", C.c_int64), ("interior_nnz", C.c_int64), ("boundary_nnz", C.c_int64),
+                ("boundary_rows", C.c_int), ("halo", C.c_int), ("send", C.c_int), ("interior_stored", C.c_int64),
+                ("interior_variant", C.c_int), ("boundary_lanes_per_row", C.c_int), ("boundary_variant", C.c_int),
+                ("device_bytes", C.c_int64)]
+
+
 # name -> (restype, argtypes); every symbol include/spmv_hip.h declares
 _vp, _i, _i64 = C.c_void_p, C.c_int, C.c_int64
 SIGNATURES = {
@@ -61,6 +69,22 @@ SIGNATURES = {
     "spmv_hip_analyze": (_i, [_vp, _i]),
     "spmv_hip_get_info": (_i, [_vp, C.POINTER(Info)]),
     "spmv_hip_download": (_i, [_vp, _i, _vp, C.c_size_t]),
+    "spmv_hip_partition_rows": (_i, [_i, _vp, _i, _i, _vp]),
+    "spmv_hip_rowblock_create": (_vp, [_i, _i, _i, _i, _i64, _vp, _vp, _vp, _i, _i64, _i64, _vp]),
+    "spmv_hip_rowblock_free": (_i, [_vp]),
+    "spmv_hip_rowblock_get_info": (_i, [_vp, C.POINTER(RowBlockInfo)]),
+    "spmv_hip_rowblock_set_option": (_i, [_vp, C.c_char_p, _i64]),
+    "spmv_hip_rowblock_halo_columns": (_i, [_vp, _vp]),
+    "spmv_hip_rowblock_set_send_list": (_i, [_vp, _i, _vp]),
+    "spmv_hip_rowblock_pack": (_i, [_vp, _vp, _vp, _vp]),
+    "spmv_hip_rowblock_mult_interior": (_i, [_vp, _vp, _vp, _vp]),
+    "spmv_hip_rowblock_mult_boundary": (_i, [_vp, _vp, _vp, _vp]),
+    "spmv_hip_dist_create": (_vp, [_i, _i, _i, _i, _vp, _i, _i64, _i64, _i, _vp]),
+    "spmv_hip_dist_mult": (_i, [_vp, _vp, _vp]),
+    "spmv_hip_dist_bench": (_i, [_vp, _i, C.c_double, _vp, C.POINTER(_i), C.POINTER(C.c_double)]),
+    "spmv_hip_dist_set_option": (_i, [_vp, C.c_char_p, _i64]),
+    "spmv_hip_dist_get_info": (_i, [_vp, C.POINTER(_i), _vp, _vp]),
+    "spmv_hip_dist_free": (_i, [_vp]),
 }
 
 _lib = None

@@ -177,6 +177,25 @@ static int finish_from_device_csr(spmv_hip_matrix *m, int64_t p0, int64_t p1, bo
     }
 }
 
+spmv_hip_matrix *adopt_device_csr(int format, int rows, int columns, int64_t nnz, int *d_row_ptr, int *d_col, void *d_val,
+                                  int dtype, int64_t p0, int64_t p1, bool own, hipStream_t stream)
+{
+    spmv_hip_matrix *m = new_handle(format, dtype, rows, columns, nnz);
+    if (!m) {
+        if (own) { (void)hipFree(d_row_ptr); (void)hipFree(d_col); (void)hipFree(d_val); }
+        return nullptr;
+    }
+    m->owns_csr = own;
+    m->stored = nnz;
+    m->d_row_ptr = d_row_ptr; m->d_col = d_col; m->d_val = d_val;
+    if (own) m->device_bytes = (int64_t)sizeof(int) * ((int64_t)rows + 1) + std::max<int64_t>(nnz, 1) * (int64_t)(sizeof(int) + dtype_size(dtype));
+    if (finish_from_device_csr(m, p0, p1, dtype == SPMV_HIP_F64, stream)) {
+        spmv_hip_free(m);
+        return nullptr;
+    }
+    return m;
+}
+
 static spmv_hip_matrix *create_from_host_csr(int format, int rows, int columns, int64_t nnz, const std::vector<int> &rp,
                                              const std::vector<int> &cj, const std::vector<double> &va, int dtype,
                                              int64_t p0, int64_t p1)

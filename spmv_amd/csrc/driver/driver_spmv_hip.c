@@ -13,6 +13,10 @@
  * a suffix the environment variable SPMV_SIGMA is consulted, then that default.
  * SPMV_EXACT_ORDER=0 lets the kernel trial also pick variants that reassociate the
  * row sums (default: only variants whose y has the same bits run to run).
+ * SPMV_NGPUS=n (n > 1) cuts every matrix into n row blocks of equal nnz shares, one
+ * per GPU, driven from this one thread (spmv_hip_dist_*); SPMV_DEVICES="0,1,.."
+ * names the devices (default 0..n-1; a device may repeat).  The CSV carries the
+ * count in its NGPUs column.
  * Per matrix of LIST the driver
  *   1. estimates the memory need like enought_memory (driver_spmv.c:50-110;
  *      .bin headers are read as binary here -- the reference parses them as text),
@@ -145,6 +149,23 @@ static spmv_hip_matrix *create_for_mode(const char *mode, int rows, int cols, in
     exit(-1);
 }
 
+/* MODE -> storage format of the interior matrices of a row-block run (the MODE chain above without
+ * the per-mode host conversions: every block is built from its CSR in HBM) */
+static int format_for_mode(const char *mode, long sigma, long *p0, long *p1)
+{
+    *p0 = *p1 = 0;
+    if (!strcmp(mode, "coo") || !strcmp(mode, "csr_base") || !strcmp(mode, "csr_autovec")) return SPMV_HIP_CSR_SCALAR;
+    if (!strcmp(mode, "csr_vec") || !strcmp(mode, "csr_highway")) return SPMV_HIP_CSR_VECTOR;
+    if (!strcmp(mode, "csr_merge")) return SPMV_HIP_CSR_MERGE;
+    if (!strcmp(mode, "csr_bal")) return SPMV_HIP_CSR_BAL;
+    if (!strcmp(mode, "ell")) return SPMV_HIP_ELL;
+    if (!strcmp(mode, "sellp_vec") || !strcmp(mode, "sellp_autovec") || !strcmp(mode, "sellp_highway")) return SPMV_HIP_SELLP;
+    if (!strcmp(mode, "sell")) { *p0 = 64; *p1 = sigma; return SPMV_HIP_SELL; }
+    if (!strcmp(mode, "sell_dfc")) { *p0 = 64; *p1 = sigma; return SPMV_HIP_SELL_DFC; }
+    printf("Error: Unknown execution mode.\n");            /* driver_spmv.c:258-260 */
+    exit(-1);
+}
+
 int main(int argc, char *argv[])
 {
     if (argc != 4) {
@@ -170,6 +191,17 @@ int main(int argc, char *argv[])
     }
     const char *exact_env = getenv("SPMV_EXACT_ORDER");
     const int exact_order = exact_env ? atoi(exact_env) != 0 : 1;
+    int ngpus = getenv("SPMV_NGPUS") ? atoi(getenv("SPMV_NGPUS")) : 1;
+    if (ngpus < 1 || ngpus > 64) { printf("Error: SPMV_NGPUS must be in 1..64\n"); exit(-1); }
+    int devices[64];
+    for (int p = 0; p < 64; p++) devices[p] = p;
+    if (getenv("SPMV_DEVICES")) {
+        char list[256];
+        snprintf(list, sizeof list, "%s", getenv("SPMV_DEVICES"));
+        int p = 0;
+        for (char *tok = strtok(list, ","); tok && p < 64; tok = strtok(NULL, ",")) devices[p++] = atoi(tok);
+        if (p < ngpus) { printf("Error: SPMV_DEVICES names %d devices, SPMV_NGPUS is %d\n", p, ngpus); exit(-1); }
+    }
     const int vbytes = dtype == SPMV_HIP_F32 ? 4 : 8;
     FILE *infd = fopen(argv[2], "r");
     if (!infd) { perror("Error openning file input for matrix list.\n"); exit(-1); }
@@ -177,8 +209,8 @@ int main(int argc, char *argv[])
     if (!outfd) { perror(argv[3]); exit(-1); }
     if (spmv_hip_init(0)) die("spmv_hip_init");
 
-    fprintf(outfd, "Format;File;Rows;Columns;NNZ;GFlops;Time(s);GB/s;PctHBMPeak;Dtype;Variant\n");
-    printf("\n  Format: %s   dtype: %s   list: %s   csv: %s\n\n", mode, dtype == SPMV_HIP_F32 ? "f32" : "f64", argv[2], argv[3]);
+    fprintf(outfd, "Format;File;Rows;Columns;NNZ;GFlops;Time(s);GB/s;PctHBMPeak;Dtype;Variant;NGPUs\n");
+    printf("\n  Format: %s   dtype: %s   GPUs: %d   list: %s   csv: %s\n\n", mode, dtype == SPMV_HIP_F32 ? "f32" : "f64", ngpus, argv[2], argv[3]);
     printf("  %-30s %10s %10s %11s | %10s %11s %9s | %8s %6s | %11s  %s\n", "Matrix", "ROWS", "COLUMNS", "NNZ", "GFlops",
            "T(s)", "Mem (Mb)", "GB/s", "%HBM", "ERROR", "Test");
 
@@ -193,8 +225,8 @@ int main(int argc, char *argv[])
         if (!enough_memory(line, &hrows, &hcols, &hnnz, &need_mb)) {      /* driver_spmv.c:332-337 */
             printf("  %-30s %10ld %10ld %11ld | %10.4f %11.4e %9lu | %8.1f %6.1f | %11.4e  ---\n", name, hrows, hcols, hnnz,
                    0.0, 0.0, need_mb, 0.0, 0.0, 0.0);
-            fprintf(outfd, "%s;%s;%ld;%ld;%ld;%.5e;%.5e;%.5e;%.2f;%s;%d\n", argv[1], name, hrows, hcols, hnnz, 0.0, 0.0, 0.0, 0.0,
-                    dtype == SPMV_HIP_F32 ? "f32" : "f64", 0);
+            fprintf(outfd, "%s;%s;%ld;%ld;%ld;%.5e;%.5e;%.5e;%.2f;%s;%d;%d\n", argv[1], name, hrows, hcols, hnnz, 0.0, 0.0, 0.0, 0.0,
+                    dtype == SPMV_HIP_F32 ? "f32" : "f64", 0, ngpus);
             continue;
         }
         int rows, columns, nnz;
@@ -204,10 +236,20 @@ int main(int argc, char *argv[])
         else { printf("Unkown file extension\n"); return 1; }
         if (rows != columns) { printf("Matrix is not square\n"); return 1; }
 
-        spmv_hip_matrix *m = create_for_mode(mode, rows, columns, nnz, coo, dtype, sigma);
-        if (!m) die("create");
-        if (spmv_hip_set_option(m, "exact_order", exact_order)) die("set_option");
-        if (spmv_hip_analyze(m, 3)) die("analyze");
+        spmv_hip_matrix *m = NULL;
+        spmv_hip_dist *dist = NULL;
+        if (ngpus > 1) {
+            long p0, p1;
+            const int format = format_for_mode(mode, sigma, &p0, &p1);
+            dist = spmv_hip_dist_create(format, rows, columns, nnz, coo, dtype, p0, p1, ngpus, devices);
+            if (!dist) die("dist_create");
+            if (spmv_hip_dist_set_option(dist, "exact_order", exact_order)) die("dist_set_option");
+        } else {
+            m = create_for_mode(mode, rows, columns, nnz, coo, dtype, sigma);
+            if (!m) die("create");
+            if (spmv_hip_set_option(m, "exact_order", exact_order)) die("set_option");
+            if (spmv_hip_analyze(m, 3)) die("analyze");
+        }
 
         double *x = (double *)malloc(sizeof(double) * (size_t)columns);
         double *y = (double *)malloc(sizeof(double) * ((size_t)rows + 64));
@@ -223,7 +265,7 @@ int main(int argc, char *argv[])
         for (int i = 0; i < rows; i++) y_ref[i] = 0.0;                    /* mult_mtx, mtx.c:270-276 */
         for (int k = 0; k < nnz; k++) y_ref[coo[k].i] += x[coo[k].j] * coo[k].a;
 
-        if (spmv_hip_mult(m, x, y)) die("mult");
+        if (dist ? spmv_hip_dist_mult(dist, x, y) : spmv_hip_mult(m, x, y)) die("mult");
         double error = 0.0, nrm = 0.0;                                    /* driver_spmv.c:278-289 */
         for (int i = 0; i < rows; i++) {
             nrm += y_ref[i] * y_ref[i];
@@ -235,23 +277,31 @@ int main(int argc, char *argv[])
         int it = 0;
         double time_spmv = 0.0;
         const char *ms = getenv("SPMV_MIN_SECONDS");                      /* default: the reference's 2 s (:303) */
-        if (spmv_hip_bench(m, 10, ms ? atof(ms) : 2.0, x, &it, &time_spmv)) die("bench");
+        if (dist ? spmv_hip_dist_bench(dist, 10, ms ? atof(ms) : 2.0, x, &it, &time_spmv)
+                 : spmv_hip_bench(m, 10, ms ? atof(ms) : 2.0, x, &it, &time_spmv)) die("bench");
         double gflops = 2.0 * nnz * it / time_spmv / 1e9;                 /* driver_spmv.c:307-308 */
         double ftime = time_spmv / it;
         double bytes = (double)nnz * (vbytes + 4) + (double)rows * (4 + vbytes) + (double)columns * vbytes;
         double gbs = bytes / ftime / 1e9;
         spmv_hip_info info;
-        spmv_hip_get_info(m, &info);
+        memset(&info, 0, sizeof info);
+        if (m) spmv_hip_get_info(m, &info);
+        else {                                             /* the interior kernel variant of block 0 */
+            spmv_hip_rowblock_info blocks[64];
+            if (spmv_hip_dist_get_info(dist, NULL, NULL, blocks) == 0) info.variant = blocks[0].interior_variant;
+        }
         const double bar = dtype == SPMV_HIP_F32 ? 1e-5 : 1e-10;          /* driver_spmv.c:313 (fp64) */
+        const double peak = HBM_PEAK_GBS * ngpus;          /* the roofline of all GPUs taking part */
         printf("  %-30s %10d %10d %11d | %10.4f %11.4e %9lu | %8.1f %6.1f | %11.4e  %s\n", name, rows, columns, nnz, gflops,
-               ftime, need_mb, gbs, 100.0 * gbs / HBM_PEAK_GBS, error, error < bar ? "OK" : "ERR");
-        fprintf(outfd, "%s;%s;%d;%d;%d;%.5e;%.5e;%.5e;%.2f;%s;%d\n", argv[1], name, rows, columns, nnz, gflops, ftime, gbs,
-                100.0 * gbs / HBM_PEAK_GBS, dtype == SPMV_HIP_F32 ? "f32" : "f64", info.variant);
+               ftime, need_mb, gbs, 100.0 * gbs / peak, error, error < bar ? "OK" : "ERR");
+        fprintf(outfd, "%s;%s;%d;%d;%d;%.5e;%.5e;%.5e;%.2f;%s;%d;%d\n", argv[1], name, rows, columns, nnz, gflops, ftime, gbs,
+                100.0 * gbs / peak, dtype == SPMV_HIP_F32 ? "f32" : "f64", info.variant, ngpus);
         fflush(outfd);
 
         free(x); free(y); free(y_ref);
         spmv_hip_free_coo(coo);
-        spmv_hip_free(m);
+        if (m) spmv_hip_free(m);
+        if (dist) spmv_hip_dist_free(dist);
     }
     printf("\n");
     fclose(infd);

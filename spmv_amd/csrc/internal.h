@@ -136,6 +136,11 @@ bool candidate_keeps_bits(const spmv_hip_matrix *m, int candidate);
 int launch_norm2(int n, const void *d_x, int dtype, double *d_out, hipStream_t stream);
 int launch_scale(int n, const void *d_y, void *d_x, int dtype, const double *d_norm, hipStream_t stream);
 
+// api.hip -- a handle over CSR arrays already in HBM; own = the handle frees them (also when the
+// creation fails), otherwise they stay the caller's
+spmv_hip_matrix *adopt_device_csr(int format, int rows, int columns, int64_t nnz, int *d_row_ptr, int *d_col, void *d_val,
+                                  int dtype, int64_t p0, int64_t p1, bool own, hipStream_t stream);
+
 // convert.hip -- build device layouts from a CSR resident in HBM.
 // `val_is_f64`: element type of d_val (host creators upload doubles; the device
 // creator hands over dtype elements).

@@ -490,8 +490,8 @@ __global__ __launch_bounds__(kBlock) void sliced64_wide_kernel(int rows, int nsl
             const bool live = P * (jj + u) + h < width;
 #pragma unroll
             for (int k = 0; k < R; k++) {
-                const T xv = x[cc[u][k]];
-                if (live) acc[k] = fma_t(xv, vv[u][k], acc[k]);    // no 0 * x here: x may be non-finite
+                const T xv = x[cc[u][k]];       // a dead column adds 0 * 0, never 0 * x: x may be non-finite
+                acc[k] = fma_t(live ? xv : (T)0, live ? vv[u][k] : (T)0, acc[k]);
             }
         }
     }

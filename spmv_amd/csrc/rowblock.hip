@@ -1,0 +1,753 @@
+// Row-block partitioned product: the matrix cut into contiguous row blocks, one per GPU.
+//
+// The reference has no partitioned product; its one partitioning precedent is the equal-nnz
+// contiguous chunking of create_csr_bal (reference src/csr_bal.c:83-85), which
+// spmv_hip_partition_rows applies to whole rows.  A block of a square matrix owns rows
+// [row_begin, row_begin + rows) and the same range of x and y.  Its rows are split into
+//   interior rows -- every column inside the block's own range: multiplied by the interior
+//                    matrix (the caller's format) against the local part of x, which needs no
+//                    communication and holds almost all non-zeros;
+//   boundary rows -- at least one column owned by another block: kept as a compact CSR with a
+//                    row map, multiplied against [x_local | halo] once the halo (the x entries
+//                    of the remote columns, sorted by global column) has arrived.  Lane-per-row
+//                    CSR when the interior format keeps mult_csr_base's summation order (so the
+//                    whole product can be bit-identical to the unpartitioned one), vector CSR
+//                    beside the reassociating formats.
+// Everything is built in HBM from the block's CSR (global column indices): one classifying pass,
+// three scans, one fill pass, a radix sort + unique of the remote columns.
+//
+// spmv_hip_rowblock_* is the per-GPU piece an exchange layer drives (one process per GPU over
+// RCCL: spmv_amd/distributed.py).  spmv_hip_dist_* drives all blocks from one host thread, one
+// stream pair per GPU, the halo pushed by peer-to-peer copies over xGMI while the interior
+// products run -- what the C driver uses.
+
+#include "internal.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_select.hpp>
+
+using namespace spmv;
+
+struct spmv_hip_rowblock {
+    int device = 0, format = 0, dtype = 0;
+    int rows = 0, row_begin = 0, columns_global = 0;
+    int64_t nnz = 0, interior_nnz = 0, boundary_nnz = 0;
+    int boundary_rows = 0, halo = 0;
+    spmv_hip_matrix *interior = nullptr;   // rows x rows, the caller's format; boundary rows are empty in it
+    spmv_hip_matrix *boundary = nullptr;   // boundary_rows x (rows + halo), lane-per-row or vector CSR with a row map
+    int *d_bnd_rows = nullptr;             // [boundary_rows] local row of each boundary row
+    int *d_halo_cols = nullptr;            // [halo] global column ids, ascending
+    int *d_send_index = nullptr;           // [nsend] local x entries other blocks need, in sending order
+    int nsend = 0;
+};
+
+namespace spmv {
+
+static inline unsigned blocks_for(int64_t n, int per = 256) { return (unsigned)std::max<int64_t>((n + per - 1) / per, 1); }
+
+// per row: how many of its entries point outside [begin, end); the row's length goes to the interior
+// or to the boundary count accordingly
+__global__ __launch_bounds__(256) void rb_classify_kernel(int rows, int begin, int end, const int *__restrict__ row_ptr,
+                                                          const int *__restrict__ col, int *__restrict__ remote_count,
+                                                          int *__restrict__ interior_count,
+                                                          int *__restrict__ boundary_count,
+                                                          int *__restrict__ boundary_flag)
+{
+    const int r = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (r > rows) return;
+    int remote = 0, len = 0;
+    if (r < rows) {
+        const int a = row_ptr[r], b = row_ptr[r + 1];
+        len = b - a;
+        for (int l = a; l < b; l++) {
+            const int c = col[l];
+            remote += c < begin || c >= end;
+        }
+    }
+    remote_count[r] = remote;                       // entry `rows` = 0 closes the scans
+    interior_count[r] = remote ? 0 : len;
+    boundary_count[r] = remote ? len : 0;
+    boundary_flag[r] = remote > 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rb_fill_kernel(int rows, int begin, int end, const int *__restrict__ row_ptr,
+                                                      const int *__restrict__ col, const T *__restrict__ val,
+                                                      const int *__restrict__ remote_pos,
+                                                      const int *__restrict__ interior_ptr,
+                                                      const int *__restrict__ boundary_pos,
+                                                      const int *__restrict__ boundary_index,
+                                                      int *__restrict__ icol, T *__restrict__ ival,
+                                                      int *__restrict__ bnd_rows, int *__restrict__ brow_ptr,
+                                                      int *__restrict__ bcol, T *__restrict__ bval,
+                                                      int *__restrict__ remote_cols)
+{
+    const int r = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (r > rows) return;
+    if (r == rows) {                                // closes the boundary row pointers
+        brow_ptr[boundary_index[rows]] = boundary_pos[rows];
+        return;
+    }
+    const int a = row_ptr[r], b = row_ptr[r + 1];
+    const bool bnd = remote_pos[r + 1] > remote_pos[r];
+    if (!bnd) {
+        int w = interior_ptr[r];
+        for (int l = a; l < b; l++, w++) { icol[w] = col[l] - begin; ival[w] = val[l]; }
+    } else {
+        const int k = boundary_index[r];
+        bnd_rows[k] = r;
+        int w = boundary_pos[r], q = remote_pos[r];
+        brow_ptr[k] = w;
+        for (int l = a; l < b; l++, w++) {
+            const int c = col[l];
+            bcol[w] = c;                            // global for now; rb_map_columns_kernel rewrites it
+            bval[w] = val[l];
+            if (c < begin || c >= end) remote_cols[q++] = c;
+        }
+    }
+}
+
+// boundary entries: a local column becomes its index in x_local, a remote one rows + its rank in the halo
+__global__ __launch_bounds__(256) void rb_map_columns_kernel(int64_t n, int rows, int begin, int end, int nhalo,
+                                                             const int *__restrict__ halo, int *__restrict__ bcol)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const int c = bcol[k];
+    if (c >= begin && c < end) { bcol[k] = c - begin; return; }
+    int lo = 0, hi = nhalo;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (halo[mid] < c) lo = mid + 1; else hi = mid;
+    }
+    bcol[k] = rows + lo;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rb_pack_kernel(int n, const int *__restrict__ index, const T *__restrict__ x,
+                                                      T *__restrict__ out)
+{
+    const int k = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (k < n) out[k] = x[index[k]];
+}
+
+// sorted unique values of d_in[0..n) -> *d_out (hipMalloc'ed), *count
+static int sort_unique(const int *d_in, int64_t n, int **d_out, int *count, hipStream_t st)
+{
+    *d_out = nullptr; *count = 0;
+    if (n == 0) return 0;
+    int *d_sorted = nullptr, *d_unique = nullptr, *d_count = nullptr;
+    void *d_temp = nullptr;
+    int rc = 1;
+    do {
+        const size_t sz = (size_t)n;
+        SPMV_HIP_TRY(hipMalloc((void **)&d_sorted, sz * sizeof(int)), break);
+        SPMV_HIP_TRY(hipMalloc((void **)&d_unique, sz * sizeof(int)), break);
+        SPMV_HIP_TRY(hipMalloc((void **)&d_count, sizeof(int)), break);
+        size_t t1 = 0, t2 = 0;
+        SPMV_HIP_TRY(rocprim::radix_sort_keys(nullptr, t1, d_in, d_sorted, sz, 0, 32, st), break);
+        SPMV_HIP_TRY(rocprim::unique(nullptr, t2, d_sorted, d_unique, d_count, sz, rocprim::equal_to<int>(), st), break);
+        SPMV_HIP_TRY(hipMalloc(&d_temp, std::max<size_t>(std::max(t1, t2), 16)), break);
+        SPMV_HIP_TRY(rocprim::radix_sort_keys(d_temp, t1, d_in, d_sorted, sz, 0, 32, st), break);
+        SPMV_HIP_TRY(rocprim::unique(d_temp, t2, d_sorted, d_unique, d_count, sz, rocprim::equal_to<int>(), st), break);
+        SPMV_HIP_TRY(hipMemcpyAsync(count, d_count, sizeof(int), hipMemcpyDeviceToHost, st), break);
+        SPMV_HIP_TRY(hipStreamSynchronize(st), break);
+        *d_out = d_unique;
+        d_unique = nullptr;
+        rc = 0;
+    } while (0);
+    void *scratch[] = {d_sorted, d_unique, d_count, d_temp};
+    for (void *p : scratch)
+        if (p) (void)hipFree(p);
+    return rc;
+}
+
+template <typename T>
+static int build_rowblock(spmv_hip_rowblock *rb, const int *d_row_ptr, const int *d_col, const T *d_val, int64_t p0,
+                          int64_t p1, hipStream_t st)
+{
+    const int rows = rb->rows, begin = rb->row_begin, end = rb->row_begin + rb->rows;
+    const size_t n1 = (size_t)rows + 1;
+    int *d_cnt[4] = {nullptr, nullptr, nullptr, nullptr};      // remote, interior, boundary counts, boundary flag
+    int *d_pos[4] = {nullptr, nullptr, nullptr, nullptr};      // their exclusive scans
+    int *icol = nullptr, *bcol = nullptr, *brp = nullptr, *d_remote = nullptr, *d_irp = nullptr;
+    T *ival = nullptr, *bval = nullptr;
+    int rc = 1;
+    do {
+        bool ok = true;
+        for (int k = 0; k < 4 && ok; k++)
+            ok = hipMalloc((void **)&d_cnt[k], n1 * sizeof(int)) == hipSuccess &&
+                 hipMalloc((void **)&d_pos[k], n1 * sizeof(int)) == hipSuccess;
+        if (!ok) { set_error("rowblock: hipMalloc of the row counters failed"); break; }
+        hipLaunchKernelGGL(rb_classify_kernel, dim3(blocks_for((int64_t)rows + 1)), dim3(256), 0, st, rows, begin, end,
+                           d_row_ptr, d_col, d_cnt[0], d_cnt[1], d_cnt[2], d_cnt[3]);
+        SPMV_HIP_TRY(hipGetLastError(), break);
+        for (int k = 0; k < 4 && ok; k++) ok = device_exclusive_scan(d_cnt[k], d_pos[k], n1, st) == 0;
+        if (!ok) break;
+        int totals[4];
+        for (int k = 0; k < 4 && ok; k++)
+            ok = hipMemcpy(&totals[k], d_pos[k] + rows, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+        if (!ok) { set_error("rowblock: reading the scan totals failed"); break; }
+        const int64_t nremote = totals[0];
+        rb->interior_nnz = totals[1];
+        rb->boundary_nnz = totals[2];
+        rb->boundary_rows = totals[3];
+        const size_t ni = (size_t)std::max<int64_t>(rb->interior_nnz, 1), nb = (size_t)std::max<int64_t>(rb->boundary_nnz, 1);
+        SPMV_HIP_TRY(hipMalloc((void **)&icol, ni * sizeof(int)), break);
+        SPMV_HIP_TRY(hipMalloc((void **)&ival, ni * sizeof(T)), break);
+        SPMV_HIP_TRY(hipMalloc((void **)&bcol, nb * sizeof(int)), break);
+        SPMV_HIP_TRY(hipMalloc((void **)&bval, nb * sizeof(T)), break);
+        SPMV_HIP_TRY(hipMalloc((void **)&brp, ((size_t)rb->boundary_rows + 1) * sizeof(int)), break);
+        SPMV_HIP_TRY(hipMalloc((void **)&rb->d_bnd_rows, (size_t)std::max(rb->boundary_rows, 1) * sizeof(int)), break);
+        SPMV_HIP_TRY(hipMalloc((void **)&d_remote, (size_t)std::max<int64_t>(nremote, 1) * sizeof(int)), break);
+        hipLaunchKernelGGL((rb_fill_kernel<T>), dim3(blocks_for((int64_t)rows + 1)), dim3(256), 0, st, rows, begin, end,
+                           d_row_ptr, d_col, d_val, d_pos[0], d_pos[1], d_pos[2], d_pos[3], icol, ival, rb->d_bnd_rows, brp,
+                           bcol, bval, d_remote);
+        SPMV_HIP_TRY(hipGetLastError(), break);
+        if (sort_unique(d_remote, nremote, &rb->d_halo_cols, &rb->halo, st)) break;
+        if (rb->boundary_nnz > 0) {
+            hipLaunchKernelGGL(rb_map_columns_kernel, dim3(blocks_for(rb->boundary_nnz)), dim3(256), 0, st, rb->boundary_nnz,
+                               rows, begin, end, rb->halo, rb->d_halo_cols, bcol);
+            SPMV_HIP_TRY(hipGetLastError(), break);
+        }
+        SPMV_HIP_TRY(hipStreamSynchronize(st), break);
+        // the interior matrix keeps all `rows` rows (boundary rows are empty in it): its row pointers are
+        // the scan of the interior counts, which the handle takes over together with icol / ival
+        d_irp = d_pos[1];
+        d_pos[1] = nullptr;
+        rb->interior = adopt_device_csr(rb->format, rows, rows, rb->interior_nnz, d_irp, icol, ival, rb->dtype, p0, p1,
+                                        /*own=*/true, st);
+        d_irp = nullptr; icol = nullptr; ival = nullptr;       // freed with (or by the failed creation of) the handle
+        if (!rb->interior) break;
+        if (spmv_hip_analyze(rb->interior, 3)) break;
+        if (rb->boundary_rows > 0) {
+            const bool exact_family = rb->format == SPMV_HIP_CSR_SCALAR || rb->format == SPMV_HIP_SELL ||
+                                      rb->format == SPMV_HIP_SELLP || rb->format == SPMV_HIP_ELL ||
+                                      rb->format == SPMV_HIP_SELL_DFC;
+            rb->boundary = adopt_device_csr(exact_family ? SPMV_HIP_CSR_SCALAR : SPMV_HIP_CSR_VECTOR, rb->boundary_rows, rows + rb->halo, rb->boundary_nnz, brp,
+                                            bcol, bval, rb->dtype, 0, 0, /*own=*/true, st);
+            brp = nullptr; bcol = nullptr; bval = nullptr;
+            if (!rb->boundary) break;
+            // the kernel trial writes y[0..boundary_rows): run it before the row map points elsewhere
+            if (spmv_hip_analyze(rb->boundary, 3)) break;
+            if (spmv_hip_set_row_map(rb->boundary, rb->d_bnd_rows)) break;
+        }
+        rc = 0;
+    } while (0);
+    void *scratch[] = {d_cnt[0], d_cnt[1], d_cnt[2], d_cnt[3], d_pos[0], d_pos[1], d_pos[2], d_pos[3], icol, ival, bcol, bval,
+                       brp, d_remote, d_irp};
+    for (void *p : scratch)
+        if (p) (void)hipFree(p);
+    return rc;
+}
+
+} // namespace spmv
+
+extern "C" {
+
+int spmv_hip_partition_rows(int rows, const int *row_ptr, int parts, int snap, int *bounds)
+{
+    clear_error();
+    if (rows < 0 || parts < 1 || !row_ptr || !bounds) { set_error("partition_rows: bad argument"); return 1; }
+    if (snap < 1) snap = 1;
+    const int64_t nnz = row_ptr[rows];
+    bounds[0] = 0;
+    for (int p = 1; p < parts; p++) {
+        const int64_t target = nnz * p / parts;
+        // first row whose row_ptr reaches the target, moved to the nearest multiple of snap
+        int64_t c = std::lower_bound(row_ptr, row_ptr + rows + 1, target, [](int v, int64_t t) { return v < t; }) - row_ptr;
+        c = (c + snap / 2) / snap * snap;
+        bounds[p] = (int)std::min<int64_t>(std::max<int64_t>(c, bounds[p - 1]), rows);
+    }
+    bounds[parts] = rows;
+    return 0;
+}
+
+spmv_hip_rowblock *spmv_hip_rowblock_create(int format, int rows, int row_begin, int columns_global, int64_t nnz,
+                                            const int *d_row_ptr, const int *d_col, const void *d_val, int dtype,
+                                            int64_t p0, int64_t p1, void *stream)
+{
+    clear_error();
+    if (rows < 0 || row_begin < 0 || nnz < 0 || (int64_t)row_begin + rows > columns_global) {
+        set_error("rowblock: rows [%d, %lld) do not lie inside the %d columns of the square matrix", row_begin,
+                  (long long)row_begin + rows, columns_global);
+        return nullptr;
+    }
+    if (dtype != SPMV_HIP_F64 && dtype != SPMV_HIP_F32) { set_error("unknown dtype %d", dtype); return nullptr; }
+    if (nnz > 0x7fffffffLL - 4096) { set_error("rowblock: %lld non-zeros exceed the 32-bit positions of one block", (long long)nnz); return nullptr; }
+    if (!d_row_ptr || (nnz > 0 && (!d_col || !d_val))) { set_error("NULL device CSR array"); return nullptr; }
+    spmv_hip_rowblock *rb = new (std::nothrow) spmv_hip_rowblock();
+    if (!rb) { set_error("out of host memory"); return nullptr; }
+    if (hipGetDevice(&rb->device) != hipSuccess) { set_error("no HIP device available"); delete rb; return nullptr; }
+    rb->format = format; rb->dtype = dtype; rb->rows = rows; rb->row_begin = row_begin; rb->columns_global = columns_global;
+    rb->nnz = nnz;
+    const int rc = dtype == SPMV_HIP_F32
+                       ? build_rowblock<float>(rb, d_row_ptr, d_col, (const float *)d_val, p0, p1, (hipStream_t)stream)
+                       : build_rowblock<double>(rb, d_row_ptr, d_col, (const double *)d_val, p0, p1, (hipStream_t)stream);
+    if (rc) {
+        char keep[512];
+        snprintf(keep, sizeof keep, "%s", spmv_hip_last_error());
+        spmv_hip_rowblock_free(rb);
+        set_error("%s", keep);
+        return nullptr;
+    }
+    return rb;
+}
+
+int spmv_hip_rowblock_free(spmv_hip_rowblock *rb)
+{
+    if (!rb) return 0;
+    DeviceGuard on(rb->device);
+    if (rb->interior) spmv_hip_free(rb->interior);
+    if (rb->boundary) spmv_hip_free(rb->boundary);
+    void *ptrs[] = {rb->d_bnd_rows, rb->d_halo_cols, rb->d_send_index};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete rb;
+    return 0;
+}
+
+int spmv_hip_rowblock_get_info(const spmv_hip_rowblock *rb, spmv_hip_rowblock_info *info)
+{
+    if (!rb || !info) { set_error("NULL argument"); return 1; }
+    memset(info, 0, sizeof *info);
+    info->format = rb->format; info->dtype = rb->dtype; info->device = rb->device;
+    info->rows = rb->rows; info->row_begin = rb->row_begin; info->columns_global = rb->columns_global;
+    info->nnz = rb->nnz; info->interior_nnz = rb->interior_nnz; info->boundary_nnz = rb->boundary_nnz;
+    info->boundary_rows = rb->boundary_rows; info->halo = rb->halo; info->send = rb->nsend;
+    spmv_hip_info mi;
+    if (rb->interior && spmv_hip_get_info(rb->interior, &mi) == 0) {
+        info->interior_stored = mi.stored; info->interior_variant = mi.variant; info->device_bytes += mi.device_bytes;
+    }
+    if (rb->boundary && spmv_hip_get_info(rb->boundary, &mi) == 0) {
+        info->boundary_lanes_per_row = mi.lanes_per_row; info->boundary_variant = mi.variant; info->device_bytes += mi.device_bytes;
+    }
+    info->device_bytes += (int64_t)sizeof(int) * ((int64_t)rb->boundary_rows + rb->halo + rb->nsend);
+    return 0;
+}
+
+int spmv_hip_rowblock_set_option(spmv_hip_rowblock *rb, const char *name, int64_t value)
+{
+    clear_error();
+    if (!rb || !name) { set_error("NULL argument"); return 1; }
+    if (strcmp(name, "exact_order")) { set_error("rowblock: unknown option '%s'", name); return 1; }
+    // the kernel trial is repeated under the new restriction
+    if (spmv_hip_set_option(rb->interior, name, value) || spmv_hip_analyze(rb->interior, 3)) return 1;
+    return 0;
+}
+
+int spmv_hip_rowblock_halo_columns(const spmv_hip_rowblock *rb, int *columns)
+{
+    clear_error();
+    if (!rb || (!columns && rb->halo > 0)) { set_error("NULL argument"); return 1; }
+    if (rb->halo == 0) return 0;
+    DeviceGuard on(rb->device);
+    if (!on.ok) return 1;
+    SPMV_HIP_TRY(hipMemcpy(columns, rb->d_halo_cols, sizeof(int) * (size_t)rb->halo, hipMemcpyDeviceToHost), return 1);
+    return 0;
+}
+
+int spmv_hip_rowblock_set_send_list(spmv_hip_rowblock *rb, int count, const int *local_index)
+{
+    clear_error();
+    if (!rb || count < 0 || (count > 0 && !local_index)) { set_error("rowblock: bad send list"); return 1; }
+    for (int k = 0; k < count; k++)
+        if (local_index[k] < 0 || local_index[k] >= rb->rows) {
+            set_error("rowblock: send list entry %d = %d is not a local row of this block (%d rows)", k, local_index[k], rb->rows);
+            return 1;
+        }
+    DeviceGuard on(rb->device);
+    if (!on.ok) return 1;
+    if (rb->d_send_index) { (void)hipFree(rb->d_send_index); rb->d_send_index = nullptr; rb->nsend = 0; }
+    if (count == 0) return 0;
+    SPMV_HIP_TRY(hipMalloc((void **)&rb->d_send_index, sizeof(int) * (size_t)count), return 1);
+    SPMV_HIP_TRY(hipMemcpy(rb->d_send_index, local_index, sizeof(int) * (size_t)count, hipMemcpyHostToDevice), return 1);
+    rb->nsend = count;
+    return 0;
+}
+
+int spmv_hip_rowblock_pack(spmv_hip_rowblock *rb, const void *d_x, void *d_send, void *stream)
+{
+    if (!rb) { set_error("NULL handle"); return 1; }
+    if (rb->nsend == 0) return 0;
+    if (!d_x || !d_send) { set_error("rowblock_pack: NULL vector"); return 1; }
+    DeviceGuard on(rb->device);
+    if (!on.ok) return 1;
+    const dim3 grid(blocks_for(rb->nsend)), block(256);
+    if (rb->dtype == SPMV_HIP_F32)
+        hipLaunchKernelGGL(rb_pack_kernel<float>, grid, block, 0, (hipStream_t)stream, rb->nsend, rb->d_send_index,
+                           (const float *)d_x, (float *)d_send);
+    else
+        hipLaunchKernelGGL(rb_pack_kernel<double>, grid, block, 0, (hipStream_t)stream, rb->nsend, rb->d_send_index,
+                           (const double *)d_x, (double *)d_send);
+    SPMV_HIP_TRY(hipGetLastError(), return 1);
+    return 0;
+}
+
+int spmv_hip_rowblock_mult_interior(spmv_hip_rowblock *rb, const void *d_x, void *d_y, void *stream)
+{
+    if (!rb) { set_error("NULL handle"); return 1; }
+    return spmv_hip_mult_dev(rb->interior, d_x, d_y, stream);
+}
+
+int spmv_hip_rowblock_mult_boundary(spmv_hip_rowblock *rb, const void *d_x_ext, void *d_y, void *stream)
+{
+    if (!rb) { set_error("NULL handle"); return 1; }
+    if (!rb->boundary) return 0;
+    return spmv_hip_mult_dev(rb->boundary, d_x_ext, d_y, stream);
+}
+
+} // extern "C"
+
+// ------------------------------------------------ all blocks from one host thread --
+
+struct spmv_hip_dist {
+    int ngpus = 0, dtype = 0, rows = 0;
+    int64_t nnz = 0;
+    std::vector<int> device, bounds;                 // bounds: ngpus+1 row boundaries
+    std::vector<spmv_hip_rowblock *> block;
+    std::vector<char *> d_x, d_y, d_send;            // per block: [x_local | halo], y, packed entries for the others
+    std::vector<double *> d_norm;
+    std::vector<hipStream_t> compute, comm;
+    std::vector<hipEvent_t> x_ready, sent;
+    // block q sends block p the entries [send_off[q][p], send_off[q][p+1]) of its send buffer; they land at
+    // halo position recv_off[p][q] of block p
+    std::vector<std::vector<int>> send_off, recv_off;
+};
+
+namespace spmv {
+
+static int dist_exchange_and_multiply(spmv_hip_dist *d)
+{
+    const size_t es = dtype_size(d->dtype);
+    const int P = d->ngpus;
+    // 1. every block packs what the others need and pushes it to them on its communication stream
+    for (int q = 0; q < P; q++) {
+        SPMV_HIP_TRY(hipSetDevice(d->device[q]), return 1);
+        SPMV_HIP_TRY(hipEventRecord(d->x_ready[q], d->compute[q]), return 1);
+        SPMV_HIP_TRY(hipStreamWaitEvent(d->comm[q], d->x_ready[q], 0), return 1);
+        if (spmv_hip_rowblock_pack(d->block[q], d->d_x[q], d->d_send[q], d->comm[q])) return 1;
+        for (int p = 0; p < P; p++) {
+            const int count = d->send_off[q][p + 1] - d->send_off[q][p];
+            if (p == q || count == 0) continue;
+            char *dst = d->d_x[p] + ((size_t)d->block[p]->rows + (size_t)d->recv_off[p][q]) * es;
+            const char *src = d->d_send[q] + (size_t)d->send_off[q][p] * es;
+            SPMV_HIP_TRY(hipMemcpyPeerAsync(dst, d->device[p], src, d->device[q], (size_t)count * es, d->comm[q]), return 1);
+        }
+        SPMV_HIP_TRY(hipEventRecord(d->sent[q], d->comm[q]), return 1);
+    }
+    // 2. interior products run meanwhile; 3. the boundary rows once every sender's pushes have landed
+    for (int p = 0; p < P; p++) {
+        SPMV_HIP_TRY(hipSetDevice(d->device[p]), return 1);
+        if (spmv_hip_rowblock_mult_interior(d->block[p], d->d_x[p], d->d_y[p], d->compute[p])) return 1;
+    }
+    for (int p = 0; p < P; p++) {
+        SPMV_HIP_TRY(hipSetDevice(d->device[p]), return 1);
+        for (int q = 0; q < P; q++)
+            if (q != p && d->send_off[q][p + 1] > d->send_off[q][p])
+                SPMV_HIP_TRY(hipStreamWaitEvent(d->compute[p], d->sent[q], 0), return 1);
+        if (spmv_hip_rowblock_mult_boundary(d->block[p], d->d_x[p], d->d_y[p], d->compute[p])) return 1;
+    }
+    return 0;
+}
+
+static int dist_sync(spmv_hip_dist *d)
+{
+    for (int p = 0; p < d->ngpus; p++) {
+        SPMV_HIP_TRY(hipSetDevice(d->device[p]), return 1);
+        SPMV_HIP_TRY(hipStreamSynchronize(d->comm[p]), return 1);
+        SPMV_HIP_TRY(hipStreamSynchronize(d->compute[p]), return 1);
+    }
+    return 0;
+}
+
+static int dist_upload_x(spmv_hip_dist *d, const double *x)
+{
+    for (int p = 0; p < d->ngpus; p++) {
+        SPMV_HIP_TRY(hipSetDevice(d->device[p]), return 1);
+        const int n = d->bounds[p + 1] - d->bounds[p];
+        if (n == 0) continue;
+        if (d->dtype == SPMV_HIP_F64) {
+            SPMV_HIP_TRY(hipMemcpy(d->d_x[p], x + d->bounds[p], sizeof(double) * (size_t)n, hipMemcpyHostToDevice), return 1);
+        } else {
+            std::vector<float> f(x + d->bounds[p], x + d->bounds[p + 1]);
+            SPMV_HIP_TRY(hipMemcpy(d->d_x[p], f.data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice), return 1);
+        }
+    }
+    return 0;
+}
+
+static int dist_download(spmv_hip_dist *d, const std::vector<char *> &src, double *out)
+{
+    for (int p = 0; p < d->ngpus; p++) {
+        SPMV_HIP_TRY(hipSetDevice(d->device[p]), return 1);
+        const int n = d->bounds[p + 1] - d->bounds[p];
+        if (n == 0) continue;
+        if (d->dtype == SPMV_HIP_F64) {
+            SPMV_HIP_TRY(hipMemcpy(out + d->bounds[p], src[p], sizeof(double) * (size_t)n, hipMemcpyDeviceToHost), return 1);
+        } else {
+            std::vector<float> f((size_t)n);
+            SPMV_HIP_TRY(hipMemcpy(f.data(), src[p], sizeof(float) * (size_t)n, hipMemcpyDeviceToHost), return 1);
+            for (int i = 0; i < n; i++) out[d->bounds[p] + i] = (double)f[(size_t)i];
+        }
+    }
+    return 0;
+}
+
+} // namespace spmv
+
+extern "C" {
+
+int spmv_hip_dist_free(spmv_hip_dist *d)
+{
+    if (!d) return 0;
+    int prev = 0;
+    const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+    for (int p = 0; p < (int)d->device.size(); p++) {
+        (void)hipSetDevice(d->device[p]);
+        if (p < (int)d->block.size() && d->block[p]) spmv_hip_rowblock_free(d->block[p]);
+        if (p < (int)d->d_x.size() && d->d_x[p]) (void)hipFree(d->d_x[p]);
+        if (p < (int)d->d_y.size() && d->d_y[p]) (void)hipFree(d->d_y[p]);
+        if (p < (int)d->d_send.size() && d->d_send[p]) (void)hipFree(d->d_send[p]);
+        if (p < (int)d->d_norm.size() && d->d_norm[p]) (void)hipFree(d->d_norm[p]);
+        if (p < (int)d->compute.size() && d->compute[p]) (void)hipStreamDestroy(d->compute[p]);
+        if (p < (int)d->comm.size() && d->comm[p]) (void)hipStreamDestroy(d->comm[p]);
+        if (p < (int)d->x_ready.size() && d->x_ready[p]) (void)hipEventDestroy(d->x_ready[p]);
+        if (p < (int)d->sent.size() && d->sent[p]) (void)hipEventDestroy(d->sent[p]);
+    }
+    if (have_prev) (void)hipSetDevice(prev);
+    delete d;
+    return 0;
+}
+
+spmv_hip_dist *spmv_hip_dist_create(int format, int rows, int columns, int nnz, struct mtx *coo, int dtype, int64_t p0,
+                                    int64_t p1, int ngpus, const int *devices)
+{
+    clear_error();
+    if (rows != columns) { set_error("dist: the partitioned product needs a square matrix (%d x %d)", rows, columns); return nullptr; }
+    if (rows < 0 || nnz < 0 || (nnz > 0 && !coo)) { set_error("dist: bad argument"); return nullptr; }
+    if (ngpus < 1 || ngpus > 64) { set_error("dist: ngpus %d out of range", ngpus); return nullptr; }
+    if (dtype != SPMV_HIP_F64 && dtype != SPMV_HIP_F32) { set_error("unknown dtype %d", dtype); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_error("no HIP device available"); return nullptr; }
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    spmv_hip_dist *d = new (std::nothrow) spmv_hip_dist();
+    if (!d) { set_error("out of host memory"); return nullptr; }
+    d->ngpus = ngpus; d->dtype = dtype; d->rows = rows; d->nnz = nnz;
+    const int P = ngpus;
+    d->device.resize(P);
+    for (int p = 0; p < P; p++) {
+        d->device[p] = devices ? devices[p] : p;
+        if (d->device[p] < 0 || d->device[p] >= ndev) {
+            set_error("dist: device %d of block %d does not exist (%d visible)", d->device[p], p, ndev);
+            delete d;
+            return nullptr;
+        }
+    }
+    d->block.assign(P, nullptr); d->d_x.assign(P, nullptr); d->d_y.assign(P, nullptr); d->d_send.assign(P, nullptr);
+    d->d_norm.assign(P, nullptr); d->compute.assign(P, nullptr); d->comm.assign(P, nullptr);
+    d->x_ready.assign(P, nullptr); d->sent.assign(P, nullptr);
+    const size_t es = dtype_size(dtype);
+    int rc = 1;
+    do {
+        // host side, as every creator: (row, col) sort in place, then row pointers
+        spmv_hip_sort_coo(nnz, coo);
+        std::vector<int> rp((size_t)rows + 1, 0);
+        bool ok = true;
+        for (int l = 0; l < nnz && ok; l++) {
+            ok = coo[l].i >= 0 && coo[l].i < rows && coo[l].j >= 0 && coo[l].j < columns;
+            if (ok) rp[(size_t)coo[l].i + 1]++;
+        }
+        if (!ok) { set_error("dist: coordinate out of range"); break; }
+        for (int r = 0; r < rows; r++) rp[(size_t)r + 1] += rp[r];
+        d->bounds.resize((size_t)P + 1);
+        // boundaries on multiples of 1024 rows: SELL sorting windows and slices never straddle two blocks
+        if (spmv_hip_partition_rows(rows, rp.data(), P, 1024, d->bounds.data())) break;
+        std::vector<std::vector<int>> halo(P);
+        for (int p = 0; p < P && ok; p++) {
+            ok = false;
+            SPMV_HIP_TRY(hipSetDevice(d->device[p]), break);
+            for (int q = 0; q < P; q++)
+                if (d->device[q] != d->device[p]) {
+                    int can = 0;
+                    if (hipDeviceCanAccessPeer(&can, d->device[p], d->device[q]) == hipSuccess && can)
+                        (void)hipDeviceEnablePeerAccess(d->device[q], 0);     // already enabled is fine
+                }
+            (void)hipGetLastError();
+            const int b = d->bounds[p], e = d->bounds[p + 1], n = e - b;
+            const int lo = rp[b], cnt = rp[e] - lo;
+            std::vector<int> lrp((size_t)n + 1), lcol((size_t)std::max(cnt, 1));
+            for (int r = 0; r <= n; r++) lrp[r] = rp[(size_t)b + r] - lo;
+            for (int l = 0; l < cnt; l++) lcol[l] = coo[(size_t)lo + l].j;
+            int *d_rp = nullptr, *d_col = nullptr;
+            char *d_val = nullptr;
+            bool up = hipMalloc((void **)&d_rp, sizeof(int) * ((size_t)n + 1)) == hipSuccess &&
+                      hipMalloc((void **)&d_col, sizeof(int) * (size_t)std::max(cnt, 1)) == hipSuccess &&
+                      hipMalloc((void **)&d_val, es * (size_t)std::max(cnt, 1)) == hipSuccess &&
+                      hipMemcpy(d_rp, lrp.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice) == hipSuccess &&
+                      (cnt == 0 || hipMemcpy(d_col, lcol.data(), sizeof(int) * (size_t)cnt, hipMemcpyHostToDevice) == hipSuccess);
+            if (up && cnt > 0) {
+                if (dtype == SPMV_HIP_F64) {
+                    std::vector<double> v((size_t)cnt);
+                    for (int l = 0; l < cnt; l++) v[l] = coo[(size_t)lo + l].a;
+                    up = hipMemcpy(d_val, v.data(), sizeof(double) * (size_t)cnt, hipMemcpyHostToDevice) == hipSuccess;
+                } else {
+                    std::vector<float> v((size_t)cnt);
+                    for (int l = 0; l < cnt; l++) v[l] = (float)coo[(size_t)lo + l].a;
+                    up = hipMemcpy(d_val, v.data(), sizeof(float) * (size_t)cnt, hipMemcpyHostToDevice) == hipSuccess;
+                }
+            }
+            if (up) d->block[p] = spmv_hip_rowblock_create(format, n, b, columns, cnt, d_rp, d_col, d_val, dtype, p0, p1, nullptr);
+            else set_error("dist: uploading block %d failed", p);
+            if (d_rp) (void)hipFree(d_rp);
+            if (d_col) (void)hipFree(d_col);
+            if (d_val) (void)hipFree(d_val);
+            if (!d->block[p]) break;
+            halo[p].resize((size_t)d->block[p]->halo);
+            if (spmv_hip_rowblock_halo_columns(d->block[p], halo[p].data())) break;
+            SPMV_HIP_TRY(hipMalloc((void **)&d->d_x[p], es * (size_t)std::max(n + d->block[p]->halo, 1)), break);
+            SPMV_HIP_TRY(hipMemset(d->d_x[p], 0, es * (size_t)std::max(n + d->block[p]->halo, 1)), break);
+            SPMV_HIP_TRY(hipMalloc((void **)&d->d_y[p], es * (size_t)std::max(n, 1)), break);
+            SPMV_HIP_TRY(hipMalloc((void **)&d->d_norm[p], sizeof(double)), break);
+            SPMV_HIP_TRY(hipStreamCreateWithFlags(&d->compute[p], hipStreamNonBlocking), break);
+            SPMV_HIP_TRY(hipStreamCreateWithFlags(&d->comm[p], hipStreamNonBlocking), break);
+            SPMV_HIP_TRY(hipEventCreateWithFlags(&d->x_ready[p], hipEventDisableTiming), break);
+            SPMV_HIP_TRY(hipEventCreateWithFlags(&d->sent[p], hipEventDisableTiming), break);
+            ok = true;
+        }
+        if (!ok) break;
+        // who sends what: block p's halo is sorted by global column, so what it needs from owner q is one
+        // contiguous piece of it; q's send buffer holds the pieces for p = 0, 1, ... in that order
+        d->send_off.assign(P, std::vector<int>((size_t)P + 1, 0));
+        d->recv_off.assign(P, std::vector<int>((size_t)P + 1, 0));
+        std::vector<std::vector<int>> send_list(P);
+        for (int p = 0; p < P; p++)
+            for (int q = 0; q < P; q++) {
+                const auto first = std::lower_bound(halo[p].begin(), halo[p].end(), d->bounds[q]);
+                const auto last = std::lower_bound(halo[p].begin(), halo[p].end(), d->bounds[q + 1]);
+                d->recv_off[p][q] = (int)(first - halo[p].begin());
+                d->recv_off[p][q + 1] = (int)(last - halo[p].begin());
+            }
+        for (int q = 0; q < P; q++)
+            for (int p = 0; p < P; p++) {
+                d->send_off[q][p] = (int)send_list[q].size();
+                if (p != q)
+                    for (int k = d->recv_off[p][q]; k < d->recv_off[p][q + 1]; k++) send_list[q].push_back(halo[p][(size_t)k] - d->bounds[q]);
+                d->send_off[q][p + 1] = (int)send_list[q].size();
+            }
+        for (int q = 0; q < P && ok; q++) {
+            ok = false;
+            SPMV_HIP_TRY(hipSetDevice(d->device[q]), break);
+            if (spmv_hip_rowblock_set_send_list(d->block[q], (int)send_list[q].size(), send_list[q].data())) break;
+            SPMV_HIP_TRY(hipMalloc((void **)&d->d_send[q], es * std::max<size_t>(send_list[q].size(), 1)), break);
+            ok = true;
+        }
+        if (!ok) break;
+        rc = 0;
+    } while (0);
+    (void)hipSetDevice(prev);
+    if (rc) {
+        char keep[512];
+        snprintf(keep, sizeof keep, "%s", spmv_hip_last_error());
+        spmv_hip_dist_free(d);
+        set_error("%s", keep);
+        return nullptr;
+    }
+    return d;
+}
+
+int spmv_hip_dist_mult(spmv_hip_dist *d, const double *x, double *y)
+{
+    clear_error();
+    if (!d || !x || !y) { set_error("NULL argument"); return 1; }
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    int rc = dist_upload_x(d, x) || dist_exchange_and_multiply(d) || dist_sync(d) || dist_download(d, d->d_y, y);
+    (void)hipSetDevice(prev);
+    return rc;
+}
+
+int spmv_hip_dist_bench(spmv_hip_dist *d, int min_iters, double min_seconds, double *x, int *iters, double *seconds)
+{
+    clear_error();
+    if (!d || !x || !iters || !seconds) { set_error("NULL argument"); return 1; }
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    int rc = 1, it = 0;
+    double total = 0.0;
+    do {
+        if (dist_upload_x(d, x) || dist_sync(d)) break;
+        const auto t0 = std::chrono::steady_clock::now();
+        bool failed = false;
+        for (;;) {
+            it++;
+            // timed: the exchange and the products of all blocks, from the first launch to the last
+            // block's completion (driver_spmv.c:297-300 times the one mult call the same way)
+            const auto t1 = std::chrono::steady_clock::now();
+            if (dist_exchange_and_multiply(d) || dist_sync(d)) { failed = true; break; }
+            const auto t2 = std::chrono::steady_clock::now();
+            total += std::chrono::duration<double>(t2 - t1).count();
+            // untimed: x = y / ||y||_2 with the norm over all blocks (driver_spmv.c:301-302)
+            double sumsq = 0.0;
+            for (int p = 0; p < d->ngpus && !failed; p++) {
+                if (hipSetDevice(d->device[p]) != hipSuccess ||
+                    launch_norm2(d->block[p]->rows, d->d_y[p], d->dtype, d->d_norm[p], d->compute[p])) { failed = true; break; }
+            }
+            for (int p = 0; p < d->ngpus && !failed; p++) {
+                double part = 0.0;
+                if (hipSetDevice(d->device[p]) != hipSuccess ||
+                    hipMemcpyAsync(&part, d->d_norm[p], sizeof part, hipMemcpyDeviceToHost, d->compute[p]) != hipSuccess ||
+                    hipStreamSynchronize(d->compute[p]) != hipSuccess) { failed = true; break; }
+                sumsq += part * part;
+            }
+            const double norm = std::sqrt(sumsq);
+            for (int p = 0; p < d->ngpus && !failed; p++) {
+                if (hipSetDevice(d->device[p]) != hipSuccess ||
+                    hipMemcpyAsync(d->d_norm[p], &norm, sizeof norm, hipMemcpyHostToDevice, d->compute[p]) != hipSuccess ||
+                    launch_scale(d->block[p]->rows, d->d_y[p], d->d_x[p], d->dtype, d->d_norm[p], d->compute[p]) ||
+                    hipStreamSynchronize(d->compute[p]) != hipSuccess) { failed = true; break; }
+            }
+            if (failed) break;
+            const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (wall > min_seconds && it >= min_iters) break;
+        }
+        if (failed) { if (!spmv_hip_last_error()[0]) set_error("dist_bench: a device call failed"); break; }
+        if (dist_download(d, d->d_x, x)) break;
+        *iters = it;
+        *seconds = total;
+        rc = 0;
+    } while (0);
+    (void)hipSetDevice(prev);
+    return rc;
+}
+
+int spmv_hip_dist_set_option(spmv_hip_dist *d, const char *name, int64_t value)
+{
+    if (!d) { set_error("NULL handle"); return 1; }
+    for (int p = 0; p < d->ngpus; p++)
+        if (spmv_hip_rowblock_set_option(d->block[(size_t)p], name, value)) return 1;
+    return 0;
+}
+
+int spmv_hip_dist_get_info(const spmv_hip_dist *d, int *ngpus, int *bounds, spmv_hip_rowblock_info *blocks)
+{
+    if (!d) { set_error("NULL handle"); return 1; }
+    if (ngpus) *ngpus = d->ngpus;
+    if (bounds)
+        for (int p = 0; p <= d->ngpus; p++) bounds[p] = d->bounds[(size_t)p];
+    if (blocks)
+        for (int p = 0; p < d->ngpus; p++)
+            if (spmv_hip_rowblock_get_info(d->block[(size_t)p], &blocks[p])) return 1;
+    return 0;
+}
+
+} // extern "C"

@@ -4,24 +4,31 @@
 The reference has no partitioned product; its only precedent is the equal-nnz
 contiguous chunking of create_csr_bal (reference src/csr_bal.c:83-85).  Here
 rank p owns a contiguous block of rows of a square matrix and the matching block
-of x and y.  One product is
+of x and y.  The block itself -- interior rows in the caller's format, boundary
+rows as a row-mapped compact CSR, the list of remote columns -- is built in HBM by
+the library (spmv_hip_rowblock_*, include/spmv_hip.h); this module adds what one
+process per GPU needs on top: who sends what to whom, and the exchange.  One
+product is
 
-    1. pack the x entries other ranks need and post the peer-to-peer exchange
-       (direct sends over xGMI, every link busy -- not a ring) on a side stream;
-    2. meanwhile multiply the INTERIOR rows (rows whose columns are all local)
-       with the local x block -- the bulk of the non-zeros;
-    3. when the halo has landed, multiply the BOUNDARY rows (compact CSR with a
-       row map) against [x_local | halo].
+    1. pack the x entries other ranks need (spmv_hip_rowblock_pack) and post the
+       peer-to-peer exchange -- one RCCL group of sends and receives, direct copies
+       over xGMI with every link busy, not a ring -- on a side stream;
+    2. meanwhile multiply the INTERIOR rows with the local x block -- the bulk of
+       the non-zeros;
+    3. when the halo has landed, multiply the BOUNDARY rows against [x_local | halo].
 
 `exchange="allgather"` is the plain alternative: all-gather the whole x, then one
 product with global column indices (no overlap; every rank receives all of x).
 
-The local products go through an `engine`; the default engine is the HIP library.
-The CPU tests inject an engine built on the oracle to exercise the partitioning
-and the exchange with gloo.
+The local work goes through an `engine`; the default engine is the HIP library.
+The CPU tests inject an engine built on the oracle to exercise the bookkeeping and
+the exchange with gloo.
 """
 from __future__ import annotations
 
+import ctypes as C
+
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -35,21 +42,30 @@ class HipEngine:
         self.dtype = dtype
         self.tdtype = torch.float64 if dtype == L.F64 else torch.float32
 
-    def matrix(self, fmt, rows, cols, rp, cj, va, p0=0, p1=0, row_map=None):
-        from .matrix import Matrix
-        nnz = int(rp[-1])
+    def _arrays(self, rp, cj, va):
         va = va.to(self.tdtype)
         if cj.numel() == 0:          # the library wants valid pointers
             cj = torch.zeros(1, dtype=torch.int32, device=rp.device)
             va = torch.zeros(1, dtype=self.tdtype, device=rp.device)
+        return rp.contiguous(), cj.contiguous(), va.contiguous()
+
+    def matrix(self, fmt, rows, cols, rp, cj, va, p0=0, p1=0):
+        from .matrix import Matrix
+        nnz = int(rp[-1])
+        rp, cj, va = self._arrays(rp, cj, va)
         st = torch.cuda.current_stream().cuda_stream
         m = Matrix.from_device_csr(fmt, rows, cols, nnz, rp.data_ptr(), cj.data_ptr(), va.data_ptr(), self.dtype,
                                    p0, p1, st, keepalive=(rp, cj, va))
-        if row_map is not None:
-            m.set_row_map(row_map.data_ptr(), keepalive=row_map)
-        else:
-            m.analyze(3)
+        m.analyze(3)
         return _HipLocal(m)
+
+    def rowblock(self, fmt, rows, row_begin, cols_global, rp, cj, va, p0=0, p1=0):
+        nnz = int(rp[-1])
+        rp, cj, va = self._arrays(rp, cj, va)
+        st = torch.cuda.current_stream().cuda_stream
+        h = L.check_handle(L.lib().spmv_hip_rowblock_create(fmt, rows, row_begin, cols_global, nnz, rp.data_ptr(),
+                                                            cj.data_ptr(), va.data_ptr(), self.dtype, p0, p1, st))
+        return _HipRowBlock(h)          # the library has copied what it keeps: rp, cj, va may go
 
 
 class _HipLocal:
@@ -62,18 +78,66 @@ class _HipLocal:
         self.m.mult_dev(x.data_ptr(), y.data_ptr(), torch.cuda.current_stream().cuda_stream)
 
 
+class _HipRowBlock:
+    """One spmv_hip_rowblock handle."""
+
+    def __init__(self, h):
+        self._h = h
+        info = L.RowBlockInfo()
+        L.check(L.lib().spmv_hip_rowblock_get_info(h, C.byref(info)))
+        self.info = info
+        self.stored = info.interior_stored + info.boundary_nnz
+        self.variant = info.interior_variant
+        halo = np.empty(max(info.halo, 1), np.int32)
+        L.check(L.lib().spmv_hip_rowblock_halo_columns(h, halo.ctypes.data_as(C.c_void_p)))
+        self.halo_columns = torch.from_numpy(halo[:info.halo].astype(np.int64))
+
+    def set_option(self, name, value):
+        L.check(L.lib().spmv_hip_rowblock_set_option(self._h, name.encode(), value))
+        info = L.RowBlockInfo()
+        L.check(L.lib().spmv_hip_rowblock_get_info(self._h, C.byref(info)))
+        self.info, self.variant = info, info.interior_variant
+
+    def set_send_list(self, index):
+        idx = np.ascontiguousarray(index.cpu().numpy(), np.int32)
+        L.check(L.lib().spmv_hip_rowblock_set_send_list(self._h, len(idx), idx.ctypes.data_as(C.c_void_p)))
+
+    def pack(self, x, send):
+        L.check(L.lib().spmv_hip_rowblock_pack(self._h, x.data_ptr(), send.data_ptr(), torch.cuda.current_stream().cuda_stream))
+
+    def mult_interior(self, x, y):
+        L.check(L.lib().spmv_hip_rowblock_mult_interior(self._h, x.data_ptr(), y.data_ptr(),
+                                                        torch.cuda.current_stream().cuda_stream))
+
+    def mult_boundary(self, x_ext, y):
+        L.check(L.lib().spmv_hip_rowblock_mult_boundary(self._h, x_ext.data_ptr(), y.data_ptr(),
+                                                        torch.cuda.current_stream().cuda_stream))
+
+    def free(self):
+        if self._h:
+            L.lib().spmv_hip_rowblock_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 def row_blocks_by_nnz(row_ptr, world: int, snap: int = 1024):
     """Contiguous row blocks with about nnz/world non-zeros each: block p ends at the first row whose
     row_ptr reaches (p+1)*nnz/world (the equal-share rule of create_csr_bal, reference
     src/csr_bal.c:83-85, on rows instead of entries), moved to the nearest multiple of `snap` rows so
-    that SELL sorting windows and slices never straddle two GPUs.  Returns world+1 boundaries."""
+    that SELL sorting windows and slices never straddle two GPUs.  Returns world+1 boundaries.
+    (spmv_hip_partition_rows is the library's form of the same rule for host row pointers.)"""
     rows = int(row_ptr.numel()) - 1
     nnz = int(row_ptr[-1])
     targets = torch.tensor([nnz * (p + 1) // world for p in range(world - 1)], dtype=row_ptr.dtype, device=row_ptr.device)
     cuts = torch.searchsorted(row_ptr.contiguous(), targets).cpu().tolist()
     bounds = [0]
     for c in cuts:
-        c = int(round(c / snap)) * snap if snap > 1 else int(c)
+        c = (int(c) + snap // 2) // snap * snap if snap > 1 else int(c)
         bounds.append(min(max(c, bounds[-1]), rows))
     bounds.append(rows)
     return bounds
@@ -83,16 +147,6 @@ def slice_row_block(row_ptr, col, val, r0: int, r1: int):
     """CSR of rows [r0, r1) of a global CSR (column indices stay global)."""
     a, b = int(row_ptr[r0]), int(row_ptr[r1])
     return (row_ptr[r0:r1 + 1] - row_ptr[r0]).to(torch.int32), col[a:b].clone(), val[a:b].clone()
-
-
-def _csr_select(rows, counts, keep_entry, cj, va):
-    """CSR of the entries flagged in keep_entry (row structure given by per-row counts)."""
-    row_of = torch.repeat_interleave(torch.arange(rows, device=cj.device), counts)
-    new_counts = torch.zeros(rows, dtype=torch.int64, device=cj.device)
-    new_counts.index_add_(0, row_of[keep_entry], torch.ones(int(keep_entry.sum()), dtype=torch.int64, device=cj.device))
-    rp = torch.zeros(rows + 1, dtype=torch.int64, device=cj.device)
-    torch.cumsum(new_counts, 0, out=rp[1:])
-    return rp.to(torch.int32), cj[keep_entry], va[keep_entry]
 
 
 class RowBlockSpmv:
@@ -114,7 +168,8 @@ class RowBlockSpmv:
         # row ranges of every rank
         # gloo cannot move device tensors: stage through the host (debug / single-GPU rehearsal only)
         self.stage_host = self.world > 1 and self.on_gpu and dist.get_backend(group) == "gloo"
-        mine = torch.tensor([row_begin, rows], dtype=torch.int64, device=dev)
+        self.comm_device = torch.device("cpu") if (self.stage_host or not self.on_gpu) else torch.device(dev)
+        mine = torch.tensor([row_begin, rows], dtype=torch.int64, device=self.comm_device)
         allr = self._all_gather(mine)
         begins = torch.stack([t[0] for t in allr]).cpu()
         counts_r = torch.stack([t[1] for t in allr]).cpu()
@@ -122,29 +177,25 @@ class RowBlockSpmv:
                 or int(begins[-1] + counts_r[-1]) != cols_global:
             raise ValueError("row blocks must be contiguous, in rank order, and cover the square matrix")
         self.begins = begins.tolist() + [cols_global]
-        my_begin, my_end = row_begin, row_begin + rows
 
-        counts = (rp[1:] - rp[:-1]).to(torch.int64)
-        cj64 = cj.to(torch.int64)
-        self.A_glob = self.A_int = self.A_bnd = None
+        self.A_glob = self.block = None
         self.nhalo = 0
         if exchange == "allgather" or self.world == 1:
             if self.world > 1 and len(set(counts_r.tolist())) != 1:
                 raise ValueError("allgather exchange needs equal row blocks")
             self.A_glob = self.engine.matrix(fmt, rows, cols_global, rp, cj, va, p0, p1)
             self.x_full = torch.zeros(cols_global, dtype=self.tdtype, device=dev)
-            self.x_local = self.x_full[my_begin:my_end] if self.world == 1 else torch.zeros(rows, dtype=self.tdtype, device=dev)
+            self.x_local = self.x_full[row_begin:row_begin + rows] if self.world == 1 \
+                else torch.zeros(rows, dtype=self.tdtype, device=dev)
             self.stored, self.variant = self.A_glob.stored, self.A_glob.variant
             return
 
         # ---- halo exchange set-up ------------------------------------------------
-        local = (cj64 >= my_begin) & (cj64 < my_end)
-        row_of = torch.repeat_interleave(torch.arange(rows, device=dev), counts)
-        bnd = torch.zeros(rows, dtype=torch.bool, device=dev)
-        bnd[row_of[~local]] = True
-        halo = torch.unique(cj64[~local])                       # sorted global column ids this rank needs
+        # the block (interior matrix, boundary rows, sorted list of remote columns) comes from the engine
+        self.block = self.engine.rowblock(fmt, rows, row_begin, cols_global, rp, cj, va, p0, p1)
+        halo = self.block.halo_columns.to(self.comm_device)       # sorted global column ids this rank needs
         self.nhalo = int(halo.numel())
-        ends = torch.tensor(self.begins[1:], dtype=torch.int64, device=dev)
+        ends = torch.tensor(self.begins[1:], dtype=torch.int64, device=self.comm_device)
         owner = torch.searchsorted(ends, halo, right=True)       # rank that owns each halo column
         need = torch.bincount(owner, minlength=self.world)       # how many I need from each rank
         need_all = self._all_gather(need)
@@ -156,52 +207,40 @@ class RowBlockSpmv:
             need_off.append(need_off[-1] + need_l[q])
         sends = {q: (halo[need_off[q]:need_off[q + 1]] - self.begins[q]).contiguous()
                  for q in range(self.world) if q != self.rank and need_l[q]}
-        recv_lists = {q: torch.empty(give[q], dtype=torch.int64, device=dev)
+        recv_lists = {q: torch.empty(give[q], dtype=torch.int64, device=self.comm_device)
                       for q in range(self.world) if q != self.rank and give[q]}
-        self._sendrecv(sends, recv_lists)
+        self._sendrecv(sends, recv_lists, staged=False)
         if self.on_gpu:
             torch.cuda.synchronize()
         self.peers_send = [q for q in range(self.world) if q != self.rank and give[q]]
         self.peers_recv = [q for q in range(self.world) if q != self.rank and need_l[q]]
         self.send_counts = {q: give[q] for q in self.peers_send}
         self.recv_ranges = {q: (need_off[q], need_off[q + 1]) for q in self.peers_recv}
-        self.send_index = torch.cat([recv_lists[q] for q in self.peers_send]) if self.peers_send else \
-            torch.empty(0, dtype=torch.int64, device=dev)
-        self.send_buf = torch.empty(self.send_index.numel(), dtype=self.tdtype, device=dev)
+        send_index = torch.cat([recv_lists[q] for q in self.peers_send]) if self.peers_send else \
+            torch.empty(0, dtype=torch.int64)
+        self.block.set_send_list(send_index)
+        self.nsend = int(send_index.numel())
+        self.send_buf = torch.empty(max(self.nsend, 1), dtype=self.tdtype, device=dev)[:self.nsend]
 
-        # ---- the two local matrices ---------------------------------------------
         self.x_ext = torch.zeros(rows + self.nhalo, dtype=self.tdtype, device=dev)
         self.x_local = self.x_ext[:rows]
         self.halo_buf = self.x_ext[rows:]
-        interior_entry = ~bnd[row_of]
-        rp_i, cj_i, va_i = _csr_select(rows, counts, interior_entry, cj64, va)
-        self.A_int = self.engine.matrix(fmt, rows, rows, rp_i, (cj_i - my_begin).to(torch.int32), va_i, p0, p1)
-        self.bnd_rows = torch.nonzero(bnd).flatten().to(torch.int32)
-        nb = int(self.bnd_rows.numel())
-        if nb:
-            cols_ext = torch.where(local, cj64 - my_begin, rows + torch.searchsorted(halo, cj64))
-            keep = ~interior_entry
-            cnt_b = counts[bnd]
-            rp_b = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
-            torch.cumsum(cnt_b, 0, out=rp_b[1:])
-            self.A_bnd = self.engine.matrix(L.CSR_VECTOR, nb, rows + self.nhalo, rp_b.to(torch.int32),
-                                            cols_ext[keep].to(torch.int32), va[keep], 0, 0, row_map=self.bnd_rows)
         self.comm_stream = torch.cuda.Stream(device=dev) if self.on_gpu else None
-        self.stored = self.A_int.stored + (self.A_bnd.stored if self.A_bnd else 0)
-        self.variant = self.A_int.variant
+        self.stored, self.variant = self.block.stored, self.block.variant
 
     # ------------------------------------------------------------------------------
     def _all_gather(self, t):
         if self.world == 1:
             return [t]
-        src = t.cpu() if self.stage_host else t
-        out = [torch.zeros_like(src) for _ in range(self.world)]
-        dist.all_gather(out, src, group=self.group)
-        return [o.to(t.device) for o in out]
+        out = [torch.zeros_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t, group=self.group)
+        return out
 
-    def _sendrecv(self, sends, recvs):
-        """Post every send and receive of one exchange together (one NCCL group: direct peer copies)."""
-        if self.stage_host:
+    def _sendrecv(self, sends, recvs, staged=None):
+        """Post every send and receive of one exchange together (one NCCL group: direct peer copies).
+        `staged`: the tensors live on the GPU while the backend is gloo -- go through the host."""
+        staged = self.stage_host if staged is None else staged
+        if staged:
             host_s = {q: t.cpu() for q, t in sends.items()}
             host_r = {q: torch.empty(t.shape, dtype=t.dtype) for q, t in recvs.items()}
         else:
@@ -211,7 +250,7 @@ class RowBlockSpmv:
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
-        if self.stage_host:
+        if staged:
             for q, t in recvs.items():
                 t.copy_(host_r[q])
 
@@ -240,20 +279,19 @@ class RowBlockSpmv:
             return y
         if x.data_ptr() != self.x_local.data_ptr():
             self.x_local.copy_(x)
-        if self.send_index.numel():
-            torch.index_select(self.x_local, 0, self.send_index, out=self.send_buf)
+        if self.nsend:
+            self.block.pack(self.x_local, self.send_buf)
         if self.on_gpu:
             main = torch.cuda.current_stream()
             self.comm_stream.wait_stream(main)
             with torch.cuda.stream(self.comm_stream):
                 self._exchange_halo()
-            self.A_int.mult(self.x_local, y)           # overlaps the exchange
+            self.block.mult_interior(self.x_local, y)           # overlaps the exchange
             main.wait_stream(self.comm_stream)
         else:
             self._exchange_halo()
-            self.A_int.mult(self.x_local, y)
-        if self.A_bnd is not None:
-            self.A_bnd.mult(self.x_ext, y)
+            self.block.mult_interior(self.x_local, y)
+        self.block.mult_boundary(self.x_ext, y)
         return y
 
     def exchange_only(self):
@@ -262,8 +300,8 @@ class RowBlockSpmv:
             if self.world > 1 and not self.stage_host:
                 dist.all_gather_into_tensor(self.x_full, self.x_local.contiguous(), group=self.group)
             return
-        if self.send_index.numel():
-            torch.index_select(self.x_local, 0, self.send_index, out=self.send_buf)
+        if self.nsend:
+            self.block.pack(self.x_local, self.send_buf)
         self._exchange_halo()
 
     def compute_only(self, y):
@@ -271,14 +309,18 @@ class RowBlockSpmv:
         if self.A_glob is not None:
             self.A_glob.mult(self.x_full, y)
             return y
-        self.A_int.mult(self.x_local, y)
-        if self.A_bnd is not None:
-            self.A_bnd.mult(self.x_ext, y)
+        self.block.mult_interior(self.x_local, y)
+        self.block.mult_boundary(self.x_ext, y)
         return y
 
     def norm2(self, v):
         """Global ||v||_2 of a row-partitioned vector (the driver's vec_norm, reference driver_spmv.c:21-26)."""
         s = torch.sum(v.to(torch.float64) ** 2).reshape(1)
         if self.world > 1:
-            dist.all_reduce(s, group=self.group)
+            if self.stage_host:
+                h = s.cpu()
+                dist.all_reduce(h, group=self.group)
+                s = h
+            else:
+                dist.all_reduce(s, group=self.group)
         return float(torch.sqrt(s))

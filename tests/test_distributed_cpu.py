@@ -19,24 +19,59 @@ from spmv_amd import generators as G
 
 
 class OracleEngine:
-    """Test-only engine: local products by oracle.mult_csr_base."""
+    """Test-only engine: local products by oracle.mult_csr_base; the row-block split restated in numpy
+    with the semantics of spmv_hip_rowblock_* (include/spmv_hip.h)."""
 
-    def matrix(self, fmt, rows, cols, rp, cj, va, p0=0, p1=0, row_map=None):
+    def matrix(self, fmt, rows, cols, rp, cj, va, p0=0, p1=0):
         import oracle
         rp_n, cj_n, va_n = rp.numpy().astype(np.int32), cj.numpy().astype(np.int32), va.numpy().astype(np.float64)
-        rm = None if row_map is None else row_map.numpy().astype(np.int64)
 
         class Local:
             stored = len(cj_n)
             variant = 0
 
             def mult(self, x, y):
-                res = oracle.mult_csr_base(rp_n, cj_n, va_n, np.ascontiguousarray(x.numpy(), np.float64))
-                if rm is None:
-                    y.numpy()[:rows] = res
-                else:
-                    y.numpy()[rm] = res
+                y.numpy()[:rows] = oracle.mult_csr_base(rp_n, cj_n, va_n, np.ascontiguousarray(x.numpy(), np.float64))
         return Local()
+
+    def rowblock(self, fmt, rows, row_begin, cols_global, rp, cj, va, p0=0, p1=0):
+        import oracle
+        rp_n, cj_n, va_n = rp.numpy().astype(np.int64), cj.numpy().astype(np.int64), va.numpy().astype(np.float64)
+        end = row_begin + rows
+        row_of = np.repeat(np.arange(rows), np.diff(rp_n))
+        remote = (cj_n < row_begin) | (cj_n >= end)
+        bnd = np.zeros(rows, bool)
+        bnd[row_of[remote]] = True
+        halo = np.unique(cj_n[remote])
+        ext = np.where(remote, rows + np.searchsorted(halo, cj_n), cj_n - row_begin).astype(np.int32)
+        keep_i = ~bnd[row_of]
+        rp_i = np.zeros(rows + 1, np.int32)
+        rp_i[1:] = np.cumsum(np.where(bnd, 0, np.diff(rp_n)))
+        bnd_rows = np.nonzero(bnd)[0]
+        rp_b = np.zeros(len(bnd_rows) + 1, np.int32)
+        rp_b[1:] = np.cumsum(np.diff(rp_n)[bnd])
+        ci, vi, cb, vb = ext[keep_i], va_n[keep_i], ext[~keep_i], va_n[~keep_i]
+
+        class Block:
+            stored = len(cj_n)
+            variant = 0
+            halo_columns = torch.from_numpy(halo.astype(np.int64))
+            send = np.zeros(0, np.int64)
+
+            def set_send_list(self, index):
+                self.send = index.numpy().astype(np.int64)
+                assert ((self.send >= 0) & (self.send < rows)).all()
+
+            def pack(self, x, send):
+                send.numpy()[:] = x.numpy()[self.send]
+
+            def mult_interior(self, x, y):
+                y.numpy()[:rows] = oracle.mult_csr_base(rp_i, ci, vi, np.ascontiguousarray(x.numpy()[:rows], np.float64))
+
+            def mult_boundary(self, x_ext, y):
+                if len(bnd_rows):
+                    y.numpy()[bnd_rows] = oracle.mult_csr_base(rp_b, cb, vb, np.ascontiguousarray(x_ext.numpy(), np.float64))
+        return Block()
 
 
 def _free_port():

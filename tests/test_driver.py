@@ -30,7 +30,8 @@ def _write_bin(path, rows, cols, coo):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["csr_base", "csr_vec", "csr_merge", "csr_bal", "sellp_vec", "ell", "sell", "sell:f32"])
+@pytest.mark.parametrize("mode", ["csr_base", "csr_vec", "csr_merge", "csr_bal", "sellp_vec", "ell", "sell", "sell:f32",
+                                  "sell:1024", "sell:64:f32"])
 def test_driver_runs_every_mode(tmp_path, mode):
     mats = []
     for name, gen in (("lap2d_40", G.laplacian2d(40)), ("stencil_9", G.stencil27(9))):
@@ -78,3 +79,49 @@ def test_driver_rejects_non_square_and_unknown_mode(tmp_path):
     open(lst, "w").write(sq + "\n")
     p = subprocess.run([DRIVER, "nonsense", lst, str(tmp_path / "o.csv")], capture_output=True, text=True, timeout=60)
     assert p.returncode == 255 and "Unknown execution mode" in p.stdout    # driver_spmv.c:258-260
+
+
+def _small_list(tmp_path):
+    mats = []
+    for name, gen in (("stencil_12", G.stencil27(12, 13, 30)), ("lap2d_70", G.laplacian2d(70)), ("powerlaw", G.power_law_rows(3000))):
+        rows, cols, rp, cj, va = gen
+        coo = G.csr_to_coo_numpy(rows, rp, cj, va)
+        path = str(tmp_path / f"{name}.bin")
+        _write_bin(path, rows, cols, coo)
+        mats.append((path, rows, len(coo)))
+    lst = str(tmp_path / "list.txt")
+    open(lst, "w").write("\n".join(m[0] for m in mats) + "\n")
+    return lst, mats
+
+
+@pytest.mark.gpu
+def test_driver_sigma_reaches_the_library(tmp_path):
+    """MODE suffix and SPMV_SIGMA select the sorting window (reference globals, sell.c:4-5); a sigma that
+    is no multiple of C is the library's error, reported like the reference's helpers do (exit 1)."""
+    lst, mats = _small_list(tmp_path)
+    env = dict(os.environ, SPMV_MIN_SECONDS="0.02")
+    for mode, extra in (("sell:1024", {}), ("sell", {"SPMV_SIGMA": "128"}), ("sell", {})):
+        p = subprocess.run([DRIVER, mode, lst, str(tmp_path / "o.csv")], capture_output=True, text=True, timeout=110,
+                           env=dict(env, **extra))
+        assert p.returncode == 0 and p.stdout.count(" OK") == len(mats), p.stdout + p.stderr
+    p = subprocess.run([DRIVER, "sell:100", lst, str(tmp_path / "o.csv")], capture_output=True, text=True, timeout=60, env=env)
+    assert p.returncode == 1 and "multiple of C" in p.stderr
+    p = subprocess.run([DRIVER, "csr_base:1024", lst, str(tmp_path / "o.csv")], capture_output=True, text=True, timeout=60, env=env)
+    assert p.returncode == 255 and "Unknown execution mode" in p.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["sell:1024", "csr_base", "csr_merge", "sellp_vec", "csr_bal:f32"])
+@pytest.mark.parametrize("ngpus", [2, 3])
+def test_driver_row_blocks_over_several_gpus(tmp_path, mode, ngpus):
+    """SPMV_NGPUS cuts every matrix into row blocks (here all on device 0): same OK verdict against the
+    host COO product, NGPUs column in the CSV."""
+    lst, mats = _small_list(tmp_path)
+    out = str(tmp_path / "out.csv")
+    env = dict(os.environ, SPMV_MIN_SECONDS="0.02", SPMV_NGPUS=str(ngpus), SPMV_DEVICES=",".join(["0"] * ngpus))
+    p = subprocess.run([DRIVER, mode, lst, out], capture_output=True, text=True, timeout=110, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = open(out).read().strip().split("\n")
+    assert lines[0].startswith(REF_HEADER) and lines[0].endswith(";NGPUs")
+    assert len(lines) == 1 + len(mats) and all(l.split(";")[-1] == str(ngpus) for l in lines[1:])
+    assert p.stdout.count(" OK") == len(mats), p.stdout
