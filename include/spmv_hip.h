@@ -309,6 +309,17 @@ int spmv_hip_bench(spmv_hip_matrix *m, int min_iters, double min_seconds, double
  * stream): calls on different streams may overlap; the first call on a
  * (device, stream) pair allocates its 8 KiB. */
 int spmv_hip_norm2_dev(int n, const void *d_x, int dtype, double *d_out, void *stream);
+/* spmv_hip_norm2_dev for callers that cannot allocate (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  Same kernels and the same bits as spmv_hip_norm2_dev, but the 1024
+ * partial sums live in an 8 KiB array that is part of the library's code object
+ * (one copy per GPU, held until the process ends), so the call allocates nothing.
+ * n is limited to 2^31 - 1 elements; a larger n is refused with an error.  The
+ * array's address is looked up once per device, by spmv_hip_init(device) or else
+ * by the first call on that device (call spmv_hip_init before capturing a graph).
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU
+ * (two streams, two threads) race; calls ordered on one stream do not. */
+int spmv_hip_norm2_dev_noalloc(int64_t n, const void *d_x, int dtype, double *d_out, void *stream);
 /* d_x[i] = d_y[i] / *d_norm */
 int spmv_hip_scale_dev(int n, const void *d_y, void *d_x, int dtype, const double *d_norm, void *stream);
 

@@ -308,7 +308,7 @@ int spmv_hip_init(int device)
 {
     clear_error();
     SPMV_HIP_TRY(hipSetDevice(device), return 1);
-    return 0;
+    return static_scratch_setup();        // so that spmv_hip_norm2_dev_noalloc has nothing left to look up
 }
 
 const char *spmv_hip_last_error(void) { return g_error; }
@@ -504,6 +504,11 @@ int spmv_hip_bench(spmv_hip_matrix *m, int min_iters, double min_seconds, double
 int spmv_hip_norm2_dev(int n, const void *d_x, int dtype, double *d_out, void *stream)
 {
     return launch_norm2(n, d_x, dtype, d_out, (hipStream_t)stream);
+}
+
+int spmv_hip_norm2_dev_noalloc(int64_t n, const void *d_x, int dtype, double *d_out, void *stream)
+{
+    return launch_norm2_static(n, d_x, dtype, d_out, (hipStream_t)stream);
 }
 
 int spmv_hip_scale_dev(int n, const void *d_y, void *d_x, int dtype, const double *d_norm, void *stream)

@@ -1442,6 +1442,49 @@ int launch_norm2(int n, const void *d_x, int dtype, double *d_out, hipStream_t s
     return launch_norm2_with(partial, n, d_x, dtype, d_out, st);
 }
 
+// ---- norm without allocation ------------------------------------------------------------------
+// The same two kernels with their partial sums in an array that is part of the code object, so the
+// entry point never allocates.  `scratch` is a host-side stand-in for the array, not a device
+// address: each GPU holds its own copy at its own address, looked up once per device (with that
+// device current) and kept in scratch_of_device; the kernels take that pointer as an argument.
+} // namespace spmv
+
+static __device__ __align__(256) double scratch[spmv::kNormBlocks];
+
+namespace spmv {
+
+static double *scratch_of_device[64] = {nullptr};
+static std::mutex scratch_lock;
+
+// Looks up the current device's copy of `scratch` (first call on that device; later calls return at once).
+int static_scratch_setup()
+{
+    int dev = 0;
+    SPMV_HIP_TRY(hipGetDevice(&dev), return 1);
+    if (dev < 0 || dev >= 64) { set_error("norm2 without allocation: device %d is beyond the 64 the library tracks", dev); return 1; }
+    std::lock_guard<std::mutex> hold(scratch_lock);
+    if (scratch_of_device[dev]) return 0;
+    double *ptr = nullptr;
+    SPMV_HIP_TRY(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)), return 1);
+    if (!ptr) { set_error("norm2 without allocation: the scratch array has no address on device %d", dev); return 1; }
+    scratch_of_device[dev] = ptr;
+    return 0;
+}
+
+int launch_norm2_static(int64_t n, const void *d_x, int dtype, double *d_out, hipStream_t st)
+{
+    if (n < 0 || n > kNormStaticMax) {
+        set_error("norm2 without allocation: n = %lld is outside 0..%lld elements", (long long)n, (long long)kNormStaticMax);
+        return 1;
+    }
+    if (dtype != SPMV_HIP_F64 && dtype != SPMV_HIP_F32) { set_error("unknown dtype %d", dtype); return 1; }
+    if (!d_out || (n > 0 && !d_x)) { set_error("norm2 without allocation: NULL vector"); return 1; }
+    if (static_scratch_setup()) return 1;
+    int dev = 0;
+    SPMV_HIP_TRY(hipGetDevice(&dev), return 1);
+    return launch_norm2_with(scratch_of_device[dev], (int)n, d_x, dtype, d_out, st);
+}
+
 int launch_scale(int n, const void *d_y, void *d_x, int dtype, const double *d_norm, hipStream_t st)
 {
     if (n <= 0) return 0;
