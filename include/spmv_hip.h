@@ -348,9 +348,10 @@ int spmv_hip_scale_dev(int n, const void *d_y, void *d_x, int dtype, const doubl
  *    cannot change results from run to run: for the sliced formats the variants
  *    that keep mult_csr_base's summation order (0, 16..23; a handle currently
  *    on a reassociating variant 1..12 is put back on 0), for vector CSR the
- *    current lanes per row and kernel family; lane-per-row CSR, merge-path and
- *    balanced tiles give the same bits under every variant.  0 (default) lifts
- *    the restriction. */
+ *    current lanes per row and kernel family, for merge-path and balanced tiles
+ *    variant 0 or variants 1 and 2 (they differ where a tile lies inside one
+ *    row); lane-per-row CSR and padding-free SELL give the same bits under every
+ *    variant.  0 (default) lifts the restriction. */
 int spmv_hip_set_option(spmv_hip_matrix *m, const char *name, int64_t value);
 /* sellcs_analyze_matrix (sell.c:30, sellcs_analyzer.c:46-120) re-thought for the
  * GPU: times every kernel variant of the handle's format `reps` times on a

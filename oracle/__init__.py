@@ -138,6 +138,20 @@ def mult_csr_base(rp, cj, va, x):
     return y
 
 
+def mult_csr_base_rows_parallel(rp, cj, va, x):
+    """mult_csr_base with the rows dealt over the OpenMP team (the pattern of csr_numa.c:3-23): every row is
+    still summed by one thread in ascending order, so the bits are those of mult_csr_base.  For the
+    full-size parity tests, where one core would take seconds per product."""
+    y = np.empty(len(rp) - 1, np.float64)
+    lib().orc_mult_csr_omp(len(rp) - 1, rp, cj, va, x, y)
+    return y
+
+
+def abs_product(rp, cj, va, x):
+    """(|A| |x|)_i -- the scale of the component-wise error bound |y - y_ref|_i <= tol * (|A||x|)_i."""
+    return mult_csr_base_rows_parallel(rp, cj, np.abs(va), np.abs(x))
+
+
 def mult_mv_csr(rp, cj, va, X):
     """X[n, columns] -> Y[n, rows]; n products of mult_csr_base."""
     X = np.ascontiguousarray(X, np.float64)

@@ -1097,7 +1097,10 @@ int variant_candidates(const spmv_hip_matrix *m, int *out, int max_out)
 // Whether `candidate` (as listed by variant_candidates) gives y the same bits as the handle's
 // current setting -- what spmv_hip_analyze may choose from under the option "exact_order".
 //   sliced formats of height 64: 0 and 16..23 keep the order of mult_csr_base; 1..12 reassociate.
-//   padding-free SELL, lane-per-row CSR, merge-path / balanced tiles: every variant sums alike.
+//   padding-free SELL, lane-per-row CSR: every variant sums alike.
+//   merge-path / balanced tiles: a tile that lies inside one row adds its entries per lane before the
+//     butterfly, and which lane holds which entry depends on where the loads start -- at the tile's
+//     first entry (variant 0) or on a 128-byte line (1, 2).
 //   vector CSR: the bits depend on the lanes per row and on the kernel family (direct loads, one
 //     fma per entry: variants 0..4; products staged in LDS, then added: 5..8).
 bool candidate_keeps_bits(const spmv_hip_matrix *m, int candidate)
@@ -1112,6 +1115,7 @@ bool candidate_keeps_bits(const spmv_hip_matrix *m, int candidate)
         const int g = candidate & 255, v = candidate >> 8;
         return g == m->lanes_per_row && (v >= 5) == (m->variant >= 5);
     }
+    if (m->format == SPMV_HIP_CSR_MERGE || m->format == SPMV_HIP_CSR_BAL) return (candidate == 0) == (m->variant == 0);
     return true;
 }
 

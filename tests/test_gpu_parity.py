@@ -627,3 +627,37 @@ def test_csr_scalar_pattern_blocks_on_grids_and_bands(orc):
             m.set_option("variant", skipping)
             assert bits_equal(m.mult(xin), y_twin), skipping
             m.free()
+
+
+def test_reassociating_kernels_meet_the_componentwise_bound(orc, g):
+    """|y - y_csr_base|_i <= 1e-12 (|A||x|)_i for every kernel that sums a row in another order than
+    mult_csr_base (reference csr.c:4-13): vector CSR (all group sizes and the LDS-staged variants),
+    merge-path and balanced tiles, the 16-byte-load sliced variants.  The rel-L2 bar alone would let a
+    single badly summed small entry hide behind large ones."""
+    rows, cols = int(g["rows"]), int(g["cols"])
+    csr = (g["csr1_row_ptr"], g["csr1_col"], g["csr1_val"])
+    bound = orc.abs_product(*csr, g["x"])
+    want = g["y_csr_base"]
+
+    def check(m, what):
+        y = m.mult(g["x"])
+        assert (np.abs(y - want) <= 1e-12 * bound).all(), (g["name"], what)
+
+    for lanes in (2, 8, 64):
+        m = Matrix.csr(rows, cols, coo_of(g), 1, S.F64, S.CSR_VECTOR, lanes)
+        for v in (0, 3, 5, 6):
+            m.set_option("variant", v)
+            check(m, ("csr_vector", lanes, v))
+        m.free()
+    for make, name in ((Matrix.csr_merge, "csr_merge"), (Matrix.csr_bal, "csr_bal")):
+        for items in (256, 2048):
+            m = make(rows, cols, coo_of(g), S.F64, items)
+            for v in (0, 1):
+                m.set_option("variant", v)
+                check(m, (name, items, v))
+            m.free()
+    for m, name in ((Matrix.sell(rows, cols, *csr, S.F64, 64, 1024), "sell"), (Matrix.sellp(rows, cols, *csr, S.F64, 64), "sellp")):
+        for v in (1, 2, 3, 4, 9, 12):
+            m.set_option("variant", v)
+            check(m, (name, v))
+        m.free()

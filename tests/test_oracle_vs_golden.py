@@ -137,3 +137,13 @@ def test_sellp_and_ell_layout_and_product(orc, g):
     for key in ("y_sellp_autovec", "y_sellp_vec", "y_ell"):
         assert bits_equal(y, g[key]), key
     assert bits_equal(y, g["y_csr_base"])
+
+
+def test_rows_parallel_product_has_the_bits_of_csr_base(orc):
+    """The OpenMP row-parallel restatement used by the full-size GPU tests is mult_csr_base bit for bit."""
+    for name in golden_names():
+        g = load_golden(name)
+        y = orc.mult_csr_base_rows_parallel(g["csr1_row_ptr"], g["csr1_col"], g["csr1_val"], g["x"])
+        assert bits_equal(y, g["y_csr_base"]), name
+        bound = orc.abs_product(g["csr1_row_ptr"], g["csr1_col"], g["csr1_val"], g["x"])
+        assert (np.abs(g["y_csr_base"]) <= bound * (1 + 1e-15) + 1e-300).all(), name
