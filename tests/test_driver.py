@@ -125,3 +125,38 @@ def test_driver_row_blocks_over_several_gpus(tmp_path, mode, ngpus):
     assert lines[0].startswith(REF_HEADER) and lines[0].endswith(";NGPUs")
     assert len(lines) == 1 + len(mats) and all(l.split(";")[-1] == str(ngpus) for l in lines[1:])
     assert p.stdout.count(" OK") == len(mats), p.stdout
+
+
+def test_default_matrix_list_is_generated_and_loads(tmp_path):
+    """matrix_lists/synthetic_5.txt is committed; its matrices come from tools/make_matrix_list.py and
+    load through the library's .bin reader (reference layout, mtx.c:139-247)."""
+    import spmv_amd as S
+    lst = os.path.join(ROOT, "matrix_lists", "synthetic_5.txt")
+    assert os.path.exists(lst)
+    p = subprocess.run(["python3", os.path.join(ROOT, "tools", "make_matrix_list.py"), "synthetic_5"], capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    paths = open(lst).read().split()
+    assert len(paths) == 5
+    for rel in paths:
+        rows, cols, coo = S.load_bin(os.path.join(ROOT, rel))
+        assert rows == cols and len(coo) > 0 and int(coo["i"].max()) < rows and int(coo["j"].max()) < cols
+    assert len(open(os.path.join(ROOT, "matrix_lists", "standins_160.txt")).read().split()) == 159
+
+
+@pytest.mark.gpu
+def test_run_script_works_out_of_the_box(tmp_path):
+    """./spmv_hip.run with its defaults (reference spmv.run:5-37): list, MODE sell, output/<count>.csv."""
+    out = str(tmp_path / "out")
+    env = dict(os.environ, OUT=out, SPMV_MIN_SECONDS="0.02")
+    for k in ("LIST", "MODE"):
+        env.pop(k, None)
+    for count in (0, 1):
+        p = subprocess.run([os.path.join(ROOT, "spmv_hip.run")], capture_output=True, text=True, timeout=200, env=env)
+        assert p.returncode == 0, p.stdout + p.stderr
+        lines = open(os.path.join(out, f"{count}.csv")).read().strip().split("\n")
+        assert lines[0].startswith(REF_HEADER) and len(lines) == 6
+        assert p.stdout.count(" OK") == 5, p.stdout
+    env["LIST"] = "matrix_lists/absent.txt"
+    p = subprocess.run([os.path.join(ROOT, "spmv_hip.run")], capture_output=True, text=True, timeout=60, env=env)
+    assert p.returncode != 0 and "not found" in p.stderr
