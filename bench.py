@@ -56,6 +56,7 @@ def parse_args(argv=None):
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--sigma", type=int, default=1024)
     ap.add_argument("--p0", type=int, default=0, help="format parameter (lanes per row / tile size / slice height)")
+    ap.add_argument("--variant", type=int, default=-1, help="N = 1: this kernel variant instead of the one the trial picks")
     ap.add_argument("--exchange", default="halo", choices=["halo", "allgather"])
     ap.add_argument("--no-comm-breakdown", action="store_true",
                     help="N > 1: skip timing the exchange alone and the local products alone after the timed region")
@@ -348,7 +349,10 @@ def main(argv=None):
     if world == 1:
         m = Matrix.from_device_csr(fmt, rows, cols, nnz, rp.data_ptr(), cj.data_ptr(), va.data_ptr(), dtype, p0, p1,
                                    stream, keepalive=(rp, cj, va))
-        m.analyze(3)           # kernel variant by trial, as create_sell does (reference sell.c:30)
+        if args.variant >= 0:
+            m.set_option("variant", args.variant)
+        else:
+            m.analyze(3)       # kernel variant by trial, as create_sell does (reference sell.c:30)
         if fmt in (S.SELL, S.SELLP, S.ELL):
             m._keepalive = None
             del rp, cj, va

@@ -485,13 +485,26 @@ __global__ __launch_bounds__(kBlock) void sliced64_wide_kernel(int rows, int nsl
             const TV *p = (const TV *)(v + (int64_t)min(P * (jj + u) + h, width - 1) * kWave);
             vv[u] = NT ? __builtin_nontemporal_load(p) : *p;
         }
+        TV xx[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int k = 0; k < R; k++) xx[u][k] = x[cc[u][k]];
+        // a step whose P columns all exist needs no mask (wave-uniform test); only the slice's last step
+        // can hold columns past the width, and those are left out of the sums, not multiplied by 0: x may
+        // be non-finite
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const bool live = P * (jj + u) + h < width;
+            if (P * (jj + u) + P <= width) {
 #pragma unroll
-            for (int k = 0; k < R; k++) {
-                const T xv = x[cc[u][k]];       // a dead column adds 0 * 0, never 0 * x: x may be non-finite
-                acc[k] = fma_t(live ? xv : (T)0, live ? vv[u][k] : (T)0, acc[k]);
+                for (int k = 0; k < R; k++) acc[k] = fma_t(xx[u][k], vv[u][k], acc[k]);
+            } else if (P * (jj + u) < width) {
+                const bool live = P * (jj + u) + h < width;
+#pragma unroll
+                for (int k = 0; k < R; k++) {
+                    const T t = fma_t(xx[u][k], vv[u][k], acc[k]);
+                    acc[k] = live ? t : acc[k];
+                }
             }
         }
     }

@@ -75,6 +75,22 @@ int main(int argc, char **argv)
         }
         return 0;
     }
+    if (argc > 1 && !strcmp(argv[1], "memtypes")) { // the same gathers from memory of other types
+        struct { const char *name; unsigned flag; } kinds[] = {{"uncached", hipDeviceMallocUncached}, {"fine-grained", hipDeviceMallocFinegrained}};
+        for (auto k : kinds) {
+            double *t2 = nullptr;
+            if (hipExtMallocWithFlags((void **)&t2, n * 8, k.flag) != hipSuccess) { printf("%s: allocation refused\n", k.name); continue; }
+            CK(hipMemset(t2, 0, n * 8));
+            printf("%s memory, 1 GiB table:\n", k.name);
+            run<0>(t2, n - 1, out, gathers); run<2>(t2, n - 1, out, gathers); run<4>(t2, n - 1, out, gathers);
+            printf("%s memory, 2 MiB table:\n", k.name);
+            run<0>(t2, ((size_t)1 << 18) - 1, out, gathers);
+            CK(hipFree(t2));
+        }
+        printf("default memory, 1 GiB table:\n");
+        run<0>(table, n - 1, out, gathers);
+        return 0;
+    }
     run<0>(table, n - 1, out, gathers); run<1>(table, n - 1, out, gathers); run<2>(table, n - 1, out, gathers);
     run<3>(table, n - 1, out, gathers); run<4>(table, n - 1, out, gathers); run<5>(table, n - 1, out, gathers);
     run<6>(table, n - 1, out, gathers); run<7>(table, n - 1, out, gathers);

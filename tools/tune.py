@@ -39,6 +39,9 @@ def main():
         rows, cols, rp, cj, va = G.stencil27(args.n, device=dev)
     elif args.matrix == "laplacian2d":
         rows, cols, rp, cj, va = G.laplacian2d(args.n, device=dev)
+    elif args.matrix.startswith("standin:"):        # a stand-in of the reference's sweep list, e.g. standin:audikw_1
+        from spmv_amd import standins
+        rows, cols, rp, cj, va = standins.standin(args.matrix.split(":", 1)[1], 1.0, device=dev)
     else:
         rows, cols, rp, cj, va = G.rmat(args.n, 16, device=dev)
     va = va.to(td)
