@@ -53,6 +53,9 @@ def parse_args(argv=None):
     ap.add_argument("--matrix", default="stencil27", choices=["stencil27", "laplacian2d", "rmat"])
     ap.add_argument("--size", dest="n", type=int, default=0, help="grid edge (stencil27: 252, laplacian2d: 1000) or R-MAT scale")
     ap.add_argument("--planes", type=int, default=0, help="N > 1: z-planes per GPU (default: the grid edge)")
+    ap.add_argument("--total-planes", type=int, default=0,
+                    help="N > 1: z-planes of the whole grid, dealt over the GPUs as evenly as they go (strong-scaling shape; "
+                         "BASELINE config 4 is --size 530 --total-planes 530)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--sigma", type=int, default=1024)
     ap.add_argument("--p0", type=int, default=0, help="format parameter (lanes per row / tile size / slice height)")
@@ -119,6 +122,19 @@ def host_cpus():
     except OSError:
         pass
     return cpus, (len(cores) or len(cpus)), model
+
+
+def l3_domains(cpus):
+    """How many last-level caches (on an EPYC host: core complexes, each with its own link to memory) the
+    allowed CPUs spread over -- the bandwidth a memory-bound OpenMP kernel can draw scales with this
+    number, not with the thread count."""
+    groups = set()
+    for c in cpus:
+        try:
+            groups.add(open(f"/sys/devices/system/cpu/cpu{c}/cache/index3/shared_cpu_list").read().strip())
+        except OSError:
+            return None
+    return len(groups)
 
 
 def cpu_baseline_child(cpu_n: int):
@@ -213,7 +229,7 @@ def cpu_baseline_child(cpu_n: int):
         "csr_merge_by_threads": {str(k): round(v, 3) for k, v in scaling.items()},
         "config1_laplacian2d_1000": {"kernel": "csr_base", "cores": 1, "value": round(c1, 3), "unit": "GFLOP/s",
                                      "rows": rows1, "nnz": len(cj1)},
-        "host": {"cpu_model": model, "logical_cpus_allowed": len(cpus), "physical_cores_allowed": physical,
+        "host": {"cpu_model": model, "logical_cpus_allowed": len(cpus), "physical_cores_allowed": physical, "l3_domains_allowed": l3_domains(cpus),
                  "omp_threads": threads, "omp_proc_bind": os.environ.get("OMP_PROC_BIND", ""),
                  "omp_places": os.environ.get("OMP_PLACES", ""), "single_thread_runs_pinned_to_cpu": cpus[0]},
     }), flush=True)
@@ -330,10 +346,17 @@ def main(argv=None):
             workload = f"stencil27 {n}^3"
         else:
             plane = n * n
-            nzp = args.planes or n          # 530^3 over 8 GPUs: --size 530 --planes 66
-            r0, r1 = rank * nzp * plane, (rank + 1) * nzp * plane
-            rows, cols, rp, cj, va = G.stencil27(n, n, nzp * world, device=dev, row_begin=r0, row_end=r1)
-            workload = f"stencil27 {n}x{n}x{nzp * world}, z-slab of {nzp} planes per GPU"
+            if args.total_planes:           # 530^3 over 8 GPUs: --size 530 --total-planes 530 (slabs of 66 or 67 planes)
+                nz_all = args.total_planes
+                p0_, p1_ = rank * nz_all // world, (rank + 1) * nz_all // world
+                workload = f"stencil27 {n}x{n}x{nz_all}, z-slabs of {nz_all // world}..{-(-nz_all // world)} planes per GPU"
+            else:
+                nzp = args.planes or n
+                nz_all = nzp * world
+                p0_, p1_ = rank * nzp, (rank + 1) * nzp
+                workload = f"stencil27 {n}x{n}x{nz_all}, z-slab of {nzp} planes per GPU"
+            r0, r1 = p0_ * plane, p1_ * plane
+            rows, cols, rp, cj, va = G.stencil27(n, n, nz_all, device=dev, row_begin=r0, row_end=r1)
     elif args.matrix == "laplacian2d":
         n = args.n or 1000
         rows, cols, rp, cj, va = G.laplacian2d(n, device=dev)
@@ -369,7 +392,7 @@ def main(argv=None):
         global_rows, global_nnz = rows, nnz
     else:
         from spmv_amd.distributed import RowBlockSpmv
-        op = RowBlockSpmv(fmt, rows, cols, rp, cj, va, dtype, p0, p1, row_begin=rank * rows, exchange=args.exchange,
+        op = RowBlockSpmv(fmt, rows, cols, rp, cj, va, dtype, p0, p1, row_begin=r0, exchange=args.exchange,
                           device=dev)
         del rp, cj, va
         torch.cuda.empty_cache()
@@ -383,10 +406,9 @@ def main(argv=None):
         def step():
             op.mult(x, y)
         stored, variant = op.stored, op.variant
-        global_rows = rows * world
-        t = torch.tensor([nnz], dtype=torch.int64, device=dev)
+        t = torch.tensor([nnz, rows], dtype=torch.int64, device=dev)
         dist.all_reduce(t)
-        global_nnz = int(t.item())
+        global_nnz, global_rows = int(t[0].item()), int(t[1].item())
 
     def timed_region(fn, steps, warmup):
         """`warmup` untimed steps, then exactly `steps` bracketed by barrier + synchronize on both sides.
@@ -488,7 +510,7 @@ def main(argv=None):
             "metric": METRIC,
             "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": "strong" if args.total_planes else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload, "format": args.format,
                        "params": {"C": 64, "sigma": args.sigma} if fmt == S.SELL else {"p0": p0},
                        "rows": global_rows, "nnz": global_nnz, "stored_per_gpu": int(stored), "kernel_variant": variant,

@@ -109,6 +109,19 @@ def test_bench_launches_its_own_ranks_gloo_rehearsal():
     assert comm["halo_entries_rank0"] == 96 * 96 and comm["exchange_alone_ms"] > 0 and "exposed_ms" in comm
 
 
+def test_bench_uneven_slabs_of_a_fixed_grid():
+    """--total-planes deals a fixed grid over the ranks (the shape of BASELINE config 4, 530^3 over 8 GPUs):
+    41 planes over 2 ranks = slabs of 20 and 21 planes, halo exchange between unequal row blocks."""
+    import json
+    p = _run_bench({"SPMV_BENCH_BACKEND": "gloo"}, "--gpus", "2", "--size", "64", "--total-planes", "41", "--steps", "3",
+                   "--warmup", "1")
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+    assert rec["config"]["rows"] == 64 * 64 * 41 and rec["scaling"] == "strong"
+    assert rec["config"]["nnz"] == (3 * 64 - 2) ** 2 * (3 * 41 - 2)
+    assert rec["communication"]["halo_entries_rank0"] == 64 * 64
+
+
 def test_bench_refuses_more_rccl_ranks_than_gpus():
     have = torch.cuda.device_count()
     p = _run_bench({}, "--gpus", str(have + 1), "--steps", "2")

@@ -75,6 +75,15 @@ int main(int argc, char **argv)
         }
         return 0;
     }
+    if (argc > 1 && !strcmp(argv[1], "l2modes")) {  // every cache policy on tables that fit the L2 / the L1
+        for (int lg : {11, 14, 18, 21}) {
+            printf("table %.0f KiB:\n", (double)((size_t)8 << lg) / 1024);
+            const size_t mask = ((size_t)1 << lg) - 1;
+            run<0>(table, mask, out, gathers); run<1>(table, mask, out, gathers); run<2>(table, mask, out, gathers);
+            run<3>(table, mask, out, gathers); run<4>(table, mask, out, gathers); run<6>(table, mask, out, gathers);
+        }
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "memtypes")) { // the same gathers from memory of other types
         struct { const char *name; unsigned flag; } kinds[] = {{"uncached", hipDeviceMallocUncached}, {"fine-grained", hipDeviceMallocFinegrained}};
         for (auto k : kinds) {

@@ -7,6 +7,7 @@ Prints per variant: median/min kernel ms (HIP events on the launch stream),
 algorithmic GB/s, and rel-L2 difference of y against variant 0.
 """
 import argparse
+import json
 import os
 import sys
 
@@ -64,7 +65,7 @@ def main():
         for var in [v if v == "auto" else int(v) for v in args.variants.split(",")]:
             if var == "auto":
                 m.analyze(3)
-                var = m.info.lanes_per_row if fmt == S.CSR_VECTOR else m.info.variant
+                var = m.info.variant
             else:
                 m.set_option("variant", var)
             for _ in range(3):
@@ -81,6 +82,11 @@ def main():
             print(f"p0={p0:6d} variant={var:3d}  median {med:8.4f} ms  min {ms[0]:8.4f} ms  "
                   f"{b_alg / med / 1e6:8.1f} GB/s alg ({b_alg / med / 1e6 / 80:.1f}% of 8 TB/s)  "
                   f"{2 * nnz / med / 1e6:8.1f} GFLOP/s  stored {m.info.stored}  relerr-vs-first {err:.2e}", flush=True)
+            info = m.info
+            print("RESULT " + json.dumps({"format": args.format, "matrix": args.matrix, "n": args.n, "dtype": args.dtype,
+                                          "hot": args.hot, "variant": info.variant, "lanes_per_row": info.lanes_per_row,
+                                          "median_ms": med, "min_ms": ms[0], "rows": rows, "cols": cols, "nnz": nnz,
+                                          "stored": info.stored, "b_alg": b_alg}), flush=True)
         m.free()
 
 
