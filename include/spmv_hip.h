@@ -90,6 +90,10 @@ typedef struct spmv_hip_info {
 
 /* Selects the device for subsequent creators on this thread (hipSetDevice). */
 int spmv_hip_init(int device);
+/* Free and total bytes of HBM on the current device (hipMemGetInfo).  The reference's
+ * driver sizes a matrix against the host's MemAvailable before loading it
+ * (enought_memory, driver_spmv.c:50-110); the C driver here asks the device as well. */
+int spmv_hip_mem_info(size_t *free_bytes, size_t *total_bytes);
 /* Message of the last failing call on this thread ("" if none). */
 const char *spmv_hip_last_error(void);
 

@@ -41,6 +41,7 @@ _vp, _i, _i64 = C.c_void_p, C.c_int, C.c_int64
 SIGNATURES = {
     "spmv_hip_init": (_i, [_i]),
     "spmv_hip_last_error": (C.c_char_p, []),
+    "spmv_hip_mem_info": (_i, [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "spmv_hip_load_mtx": (_i, [C.c_char_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_vp)]),
     "spmv_hip_free_coo": (None, [_vp]),
     "spmv_hip_load_bin": (_i, [C.c_char_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_vp)]),

@@ -313,6 +313,16 @@ int spmv_hip_init(int device)
 
 const char *spmv_hip_last_error(void) { return g_error; }
 
+int spmv_hip_mem_info(size_t *free_bytes, size_t *total_bytes)
+{
+    clear_error();
+    size_t f = 0, t = 0;
+    SPMV_HIP_TRY(hipMemGetInfo(&f, &t), return 1);
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return 0;
+}
+
 spmv_hip_matrix *spmv_hip_create_csr(int rows, int columns, int nnz, int alignment, struct mtx *coo, int dtype,
                                      int kernel, int lanes_per_row)
 {

@@ -83,6 +83,8 @@ static int has_suffix(const char *s, const char *suffix)
     return a >= b && strcmp(s + a - b, suffix) == 0;
 }
 
+static int g_ngpus = 1;
+
 /* Sizes from the file header, and the reference's estimate 2*16*nnz + 8*(rows+cols) bytes in MB. */
 static int enough_memory(const char *path, long *rows, long *cols, long *nnz, unsigned long *need_mb)
 {
@@ -105,7 +107,13 @@ static int enough_memory(const char *path, long *rows, long *cols, long *nnz, un
     unsigned long bytes = 2ul * (unsigned long)*nnz * 16ul + (unsigned long)(*rows + *cols) * 8ul;
     *need_mb = bytes / (1024 * 1024);
     unsigned long free_mb = available_memory_kb() / 1024;
-    return *need_mb < free_mb * 0.95;
+    if (!(*need_mb < free_mb * 0.95)) return 0;
+    /* the device holds the CSR arrays and the format built from them at the same time: about the same
+     * 2 * 16 bytes per entry, against what is free in HBM (all GPUs of a row-block run together) */
+    size_t hbm_free = 0;
+    if (spmv_hip_mem_info(&hbm_free, NULL) == 0 && hbm_free > 0)
+        return (double)*need_mb < (double)(hbm_free / (1024 * 1024)) * 0.95 * g_ngpus;
+    return 1;
 }
 
 /* COO -> plain CSR arrays on the host, for the creators that take CSR (the reference driver gets them from create_csr, driver_spmv.c:207,243) */
@@ -193,6 +201,7 @@ int main(int argc, char *argv[])
     const int exact_order = exact_env ? atoi(exact_env) != 0 : 1;
     int ngpus = getenv("SPMV_NGPUS") ? atoi(getenv("SPMV_NGPUS")) : 1;
     if (ngpus < 1 || ngpus > 64) { printf("Error: SPMV_NGPUS must be in 1..64\n"); exit(-1); }
+    g_ngpus = ngpus;
     int devices[64];
     for (int p = 0; p < 64; p++) devices[p] = p;
     if (getenv("SPMV_DEVICES")) {

@@ -111,6 +111,33 @@ def test_driver_sigma_reaches_the_library(tmp_path):
 
 
 @pytest.mark.gpu
+def test_driver_skips_what_does_not_fit_in_device_memory(tmp_path):
+    """A matrix whose estimate (2*16*nnz + 8*(rows+cols) bytes, driver_spmv.c:332-337) exceeds the free
+    device memory gets the reference's zero row and the sweep goes on with the next file."""
+    from spmv_amd import _lib
+    import ctypes
+    free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    assert _lib.lib().spmv_hip_mem_info(ctypes.byref(free), ctypes.byref(total)) == 0
+    assert 0 < free.value <= total.value
+    nnz = int(total.value) // 16                    # estimate = 2 * total: does not fit whatever the host has
+    big = str(tmp_path / "too_big.mtx")
+    open(big, "w").write(f"%%MatrixMarket matrix coordinate real general\n2000000000 2000000000 {nnz}\n")
+    rows, cols, rp, cj, va = G.laplacian2d(30)
+    small = str(tmp_path / "lap2d_30.mtx")
+    G.write_mtx(small, rows, cols, G.csr_to_coo_numpy(rows, rp, cj, va))
+    lst = str(tmp_path / "list.txt")
+    open(lst, "w").write(big + "\n" + small + "\n")
+    out = str(tmp_path / "o.csv")
+    p = subprocess.run([DRIVER, "csr_base", lst, out], capture_output=True, text=True, timeout=110,
+                       env=dict(os.environ, SPMV_MIN_SECONDS="0.02"))
+    assert p.returncode == 0, p.stdout + p.stderr
+    verdicts = [l.split()[-1] for l in p.stdout.splitlines() if l.strip() and l.split()[-1] in ("OK", "ERR", "---")]
+    assert verdicts == ["---", "OK"], p.stdout
+    lines = open(out).read().strip().split("\n")
+    assert len(lines) == 3 and float(lines[1].split(";")[5]) == 0.0 and float(lines[2].split(";")[5]) > 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["sell:1024", "csr_base", "csr_merge", "sellp_vec", "csr_bal:f32"])
 @pytest.mark.parametrize("ngpus", [2, 3])
 def test_driver_row_blocks_over_several_gpus(tmp_path, mode, ngpus):
