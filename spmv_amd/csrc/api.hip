@@ -308,6 +308,17 @@ int spmv_hip_init(int device)
 {
     clear_error();
     SPMV_HIP_TRY(hipSetDevice(device), return 1);
+    // The block -> XCD remap of the kernels (xcd_contiguous_block) and the per-XCD column split of
+    // hot_columns 2 assume the 8 XCDs x 32 CUs of one whole MI355X.  In another compute partition the remap
+    // is still a bijection, so results do not change; only the L2 locality it was built for is lost.
+    int cus = 0;
+    SPMV_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device), return 1);
+    static bool warned = false;
+    if (cus != 256 && !warned) {
+        warned = true;
+        fprintf(stderr, "spmv_hip: device %d shows %d compute units, not the 256 (8 XCDs) the block placement is "
+                        "tuned for; results are unaffected\n", device, cus);
+    }
     return static_scratch_setup();        // so that spmv_hip_norm2_dev_noalloc has nothing left to look up
 }
 
