@@ -86,6 +86,7 @@ typedef struct spmv_hip_info {
                              one distance from the diagonal; the variants >= 16 do not read their indices */
     int     pattern_blocks; /* CSR_SCALAR: blocks of 64 rows that repeat one pattern of distances from the
                              diagonal; the variants >= 16 read one row's indices for each */
+    int     hot_variant;  /* with hot_columns 2: tile kernel of the copy split by column group (option "hot_variant") */
 } spmv_hip_info;
 
 /* Selects the device for subsequent creators on this thread (hipSetDevice). */
@@ -346,7 +347,14 @@ int spmv_hip_scale_dev(int n, const void *d_y, void *d_x, int dtype, const doubl
  *    from the plain product by reassociation (tolerance parity).  Costs
  *    (4 + V) bytes per entry plus (36 + 8 V) bytes per row of HBM; pays once x
  *    is far larger than the eight L2s together (R-MAT scale 26: 20.1 ms
- *    plain, 12.0 ms with 1, 9.7 ms with 2).
+ *    plain, 12.0 ms with 1, 8.7 ms with 2).
+ *  "hot_variant" = tile kernel of that second copy (needs "hot_columns" = 2;
+ *    spmv_hip_analyze picks it by trial): 0, 1 = the balanced-CSR kernels, one
+ *    workgroup per tile; 3, 4 = persistent workgroups of 8 / 16 waves, one per
+ *    CU, that keep the first 14336 / 8192 labels (fp64; fp32: 32768 / 24576)
+ *    of their column group's share of x in LDS -- a gather served there saves
+ *    the 128-byte line an L2 hit moves into the L1.  1, 3 and 4 give the same
+ *    bits.
  *  "exact_order" = 1: spmv_hip_analyze may only pick kernel variants that leave
  *    the bits of y as they are under the current setting, so that tuning noise
  *    cannot change results from run to run: for the sliced formats the variants

@@ -475,7 +475,7 @@ int spmv_hip_free(spmv_hip_matrix *m)
     release_csr(m);
     void *ptrs[] = {m->d_tile_coord, m->d_row_carry, m->d_val_carry, m->d_nzr_id, m->d_nzr_end, m->d_slice_ptr,
                     m->d_row_order, m->d_slice_ident, m->d_scol, m->d_sval, m->d_sorted_len, m->d_vop_ptr, m->d_vop_len,
-                    m->d_x, m->d_y, m->d_norm, m->d_hot_col, m->d_hot_old, m->d_hot_x, m->d_xcd_y, m->d_sdiag, m->d_block_pat, m->d_tile_pat};
+                    m->d_x, m->d_y, m->d_norm, m->d_hot_col, m->d_hot_old, m->d_hot_x, m->d_xcd_y, m->d_xcd_presence, m->d_sdiag, m->d_block_pat, m->d_tile_pat};
     if (m->xcd_sub) spmv_hip_free(m->xcd_sub);
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -544,7 +544,9 @@ static void drop_hot_columns(spmv_hip_matrix *m)
         m->xcd_bytes = 0;
         spmv_hip_free(m->xcd_sub);
         (void)hipFree(m->d_hot_old); (void)hipFree(m->d_hot_x); (void)hipFree(m->d_xcd_y);
+        (void)hipFree(m->d_xcd_presence);
         m->xcd_sub = nullptr; m->d_hot_old = nullptr; m->d_hot_x = nullptr; m->d_xcd_y = nullptr; m->xcd_cpx = 0;
+        m->d_xcd_presence = nullptr;
         return;
     }
     if (!m->d_hot_col) return;
@@ -563,6 +565,7 @@ static int build_xcd_split(spmv_hip_matrix *m, hipStream_t st)
     const int64_t es = (int64_t)dtype_size(m->dtype), labels = 8 * (int64_t)cpx;
     spmv_hip_matrix *sub = new_handle(SPMV_HIP_CSR_BAL, m->dtype, 8 * m->rows, (int)labels, m->nnz);
     void *xh = nullptr, *yp = nullptr;
+    unsigned char *presence = nullptr;
     int rc = 1;
     do {
         if (!sub) break;
@@ -573,17 +576,36 @@ static int build_xcd_split(spmv_hip_matrix *m, hipStream_t st)
         vrp = nullptr; vcol = nullptr; vval = nullptr;                    // the handle frees them from here on
         if (finish_from_device_csr(sub, 0, 0, m->dtype == SPMV_HIP_F64, st)) break;
         sub->leave_empty_rows = true;                                     // the final sum skips empty virtual rows
+        {
+            // where each group's piece starts in the tiles: piece g begins at entry vrow_ptr[g * rows]
+            int first_entry[9];
+            hipError_t copied = hipSuccess;
+            for (int g = 0; g <= 8 && copied == hipSuccess; g++)
+                copied = hipMemcpyAsync(&first_entry[g], sub->d_row_ptr + (size_t)g * m->rows, sizeof(int),
+                                        hipMemcpyDeviceToHost, st);
+            SPMV_HIP_TRY(copied, break);
+            SPMV_HIP_TRY(hipStreamSynchronize(st), break);
+            if (sub->items_per_tile > 0) {
+                for (int g = 0; g < 8; g++) sub->group_first_tile[g] = std::min(first_entry[g] / sub->items_per_tile, sub->ntiles);
+                sub->group_first_tile[0] = 0;
+                sub->group_first_tile[8] = sub->ntiles;
+                sub->group_cpx = cpx;
+            }
+        }
         SPMV_HIP_TRY(hipMalloc(&xh, (size_t)(labels * es)), break);
         SPMV_HIP_TRY(hipMalloc(&yp, (size_t)(8 * (int64_t)m->rows * es)), break);
+        SPMV_HIP_TRY(hipMalloc((void **)&presence, (size_t)m->rows), break);
+        if (launch_group_presence(m->rows, sub->d_row_ptr, presence, st)) break;
+        SPMV_HIP_TRY(hipStreamSynchronize(st), break);
         m->xcd_sub = sub; m->xcd_cpx = cpx;
-        m->d_hot_old = old_of_label; m->d_hot_x = xh; m->d_xcd_y = yp;
-        m->xcd_bytes = sub->device_bytes + labels * (4 + es) + 8 * (int64_t)m->rows * es;
+        m->d_hot_old = old_of_label; m->d_hot_x = xh; m->d_xcd_y = yp; m->d_xcd_presence = presence;
+        m->xcd_bytes = sub->device_bytes + labels * (4 + es) + 8 * (int64_t)m->rows * es + m->rows;
         m->device_bytes += m->xcd_bytes;
-        sub = nullptr; old_of_label = nullptr; xh = nullptr; yp = nullptr;
+        sub = nullptr; old_of_label = nullptr; xh = nullptr; yp = nullptr; presence = nullptr;
         rc = 0;
     } while (0);
     if (sub) spmv_hip_free(sub);
-    void *scratch[] = {vrp, vcol, vval, old_of_label, xh, yp};
+    void *scratch[] = {vrp, vcol, vval, old_of_label, xh, yp, presence};
     for (void *p : scratch)
         if (p) (void)hipFree(p);
     return rc;
@@ -596,6 +618,11 @@ int spmv_hip_set_option(spmv_hip_matrix *m, const char *name, int64_t value)
     DeviceGuard on(m->device);
     if (!on.ok) return 1;
     if (!strcmp(name, "variant")) { m->variant = (int)value; return 0; }
+    if (!strcmp(name, "hot_variant")) {                     // the tile kernel of the stacked matrix behind hot_columns 2
+        if (!m->xcd_sub) { set_error("hot_variant needs hot_columns 2"); return 1; }
+        m->xcd_sub->variant = (int)value;
+        return 0;
+    }
     if (!strcmp(name, "exact_order")) {
         m->exact_order = value != 0;
         // sliced formats: leave the reassociating 16-byte-load variants for the exact-order kernel
@@ -830,6 +857,7 @@ int spmv_hip_get_info(const spmv_hip_matrix *m, spmv_hip_info *info)
     info->hot_columns = m->xcd_sub ? 2 : (m->d_hot_col != nullptr);
     info->diag_columns = m->diag_columns;
     info->pattern_blocks = m->pat_blocks;
+    info->hot_variant = m->xcd_sub ? m->xcd_sub->variant : 0;
     return 0;
 }
 

@@ -113,7 +113,12 @@ struct spmv_hip_matrix {
     // stacked matrix of 8*rows virtual rows and 8*xcd_cpx labels; d_hot_old / d_hot_x then have one
     // entry per label, d_xcd_y holds the 8 partial results of every row
     spmv_hip_matrix *xcd_sub = nullptr;
+    // on the stacked handle itself: labels per column group (0 = not a stacked matrix) and the first
+    // tile of each group's piece ([8] = ntiles), for the tile kernels that keep hot labels in LDS
+    int group_cpx = 0;
+    int group_first_tile[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     void *d_xcd_y = nullptr;
+    unsigned char *d_xcd_presence = nullptr;        // per row: bit g set when column group g has entries in the row
     int xcd_cpx = 0;
     int64_t xcd_bytes = 0;          // what the stacked handle and its vectors added to device_bytes
 
@@ -148,6 +153,7 @@ spmv_hip_matrix *adopt_device_csr(int format, int rows, int columns, int64_t nnz
 // `val_is_f64`: element type of d_val (host creators upload doubles; the device
 // creator hands over dtype elements).
 int choose_lanes_per_row(int rows, int64_t stored);
+int launch_group_presence(int rows, const int *d_vrow_ptr, unsigned char *d_presence, hipStream_t stream);   // kernels.hip
 int build_hot_columns(spmv_hip_matrix *m, hipStream_t stream);                            // sort.hip
 int build_xcd_columns(const spmv_hip_matrix *m, bool val_is_f64, hipStream_t stream, int **vrow_ptr, int **vcol,
                       void **vval, int **old_of_label, int *cpx);                         // sort.hip

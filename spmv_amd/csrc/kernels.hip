@@ -944,6 +944,166 @@ __global__ void tile_fixup_kernel(int ntiles, int list_len, const int *__restric
     y[row] = acc;
 }
 
+// ---- balanced tiles with the hottest columns of each column group in LDS ----
+//
+// For the stacked matrix of the option "hot_columns" = 2 (sort.hip): piece g of the tiles only names
+// the labels g*cpx .. g*cpx+cpx-1 of the permuted x, the most referenced first.  A gather that hits
+// the L2 still costs a 128-byte line transfer into the L1 for 8 bytes of x, and on a power-law
+// matrix those transfers, not HBM, take most of the time of the hits.  Here the workgroups are
+// persistent, one per CU: workgroup b serves group b % 8 (workgroups b, b+8, ... share an XCD), loads
+// the group's first kHot labels of x into LDS once and then walks its share of the group's tiles, W
+// tiles at a time, one per wave.  A column below the mark is read from LDS, any other (the cold
+// rest, or another group's in a tile that straddles two pieces) from memory as before.  Everything
+// after the gather is wave_tile_kernel's (line-aligned loads, products, row sums in ascending
+// order, carries), so y has the bits of that kernel's MODE 2.  The waves never wait for each other
+// after the first barrier: each owns its staging arrays, and LDS operations of one wave complete
+// in order.
+struct tile_groups { int first_tile[9]; };
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename T, int IPL, int W> struct hot_tile_shape {
+    static constexpr int kCap = kWave * IPL;
+    static constexpr int kStageBytes = W * kCap * (int)(sizeof(T) + sizeof(int));
+    static constexpr int kHot = (160 * 1024 - kStageBytes) / (int)sizeof(T);      // all of the CU's LDS
+};
+
+template <typename T, int IPL, int W>
+__global__ __launch_bounds__(kWave * W) void wave_tile_hot_kernel(const int *__restrict__ row_end_list,
+                                                                  const int *__restrict__ row_index,
+                                                                  const int *__restrict__ tile_coord,
+                                                                  const int *__restrict__ col,
+                                                                  const T *__restrict__ val,
+                                                                  const T *__restrict__ x, T *__restrict__ y,
+                                                                  int *__restrict__ row_carry,
+                                                                  T *__restrict__ val_carry, tile_groups groups,
+                                                                  int cpx, int nnz)
+{
+    using shape = hot_tile_shape<T, IPL, W>;
+    constexpr int kCap = shape::kCap;
+    constexpr int kHot = shape::kHot;
+    __shared__ T hot[kHot];
+    __shared__ T prod_of_wave[W][kCap];
+    __shared__ int rend_of_wave[W][kCap];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int g = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int hot_base = g * cpx;
+    const int nhot = min(kHot, cpx);
+    for (int i = threadIdx.x; i < nhot; i += kWave * W) hot[i] = x[hot_base + i];
+    __syncthreads();
+    T *prod = prod_of_wave[wave];
+    int *rend = rend_of_wave[wave];
+    const int t_begin = groups.first_tile[g] + slot * W + wave, t_end = groups.first_tile[g + 1];
+    const int stride = slots * W;
+    constexpr int kLoads = IPL + 1;
+    // balanced tiles are equal shares of the entries: tile t holds entries t*kCap .. min(t*kCap + kCap, nnz) - 1
+    auto issue_loads = [&](int t, int (&cc)[kLoads], T (&vv)[kLoads]) {
+        const int b0 = (int)min((int64_t)t * kCap, (int64_t)nnz - 1);
+        const int nz = min(kCap, nnz - b0);
+        const int first = (b0 & ~31) - b0;
+#pragma unroll
+        for (int i = 0; i < kLoads; i++)
+            cc[i] = __builtin_nontemporal_load(col + b0 + min(max(first + lane + i * kWave, 0), nz - 1));
+#pragma unroll
+        for (int i = 0; i < kLoads; i++)
+            vv[i] = __builtin_nontemporal_load(val + b0 + min(max(first + lane + i * kWave, 0), nz - 1));
+    };
+    // One tile: its gathers, then the stream loads of the wave's next tile (issued whether or not there is
+    // one -- the last tile's are repeated -- so that they are in flight while the gathers are waited for),
+    // then products, row sums and carries as in wave_tile_kernel.
+    auto tile = [&](int t, int (&cc)[kLoads], T (&vv)[kLoads], int (&cn)[kLoads], T (&vn)[kLoads]) {
+        const int a0 = tile_coord[2 * t], b0 = tile_coord[2 * t + 1];
+        const int a1 = tile_coord[2 * t + 2], b1 = tile_coord[2 * t + 3];
+        const int nr = a1 - a0, nz = b1 - b0;
+        const int first = (b0 & ~31) - b0;
+        T xx[kLoads], pp[kLoads];
+#pragma unroll
+        for (int i = 0; i < kLoads; i++) {
+            const unsigned rel = (unsigned)(cc[i] - hot_base);
+            if (rel < (unsigned)nhot) xx[i] = hot[rel];
+            else xx[i] = x[cc[i]];
+        }
+        issue_loads(min(t + stride, t_end - 1), cn, vn);
+#pragma unroll
+        for (int i = 0; i < kLoads; i++) {
+            const int k = first + lane + i * kWave;
+            pp[i] = k >= 0 && k < nz ? vv[i] * xx[i] : (T)0;
+        }
+        if (nr == 0) {                               // the tile is a piece of one row
+            T s = 0;
+#pragma unroll
+            for (int i = 0; i < kLoads; i++) s += pp[i];
+            s = group_sum<kWave>(s);
+            if (lane == 0) { row_carry[t] = a1; val_carry[t] = s; }
+            return;
+        }
+        wave_lds_fence();                            // the previous tile's row sums have read their products
+#pragma unroll
+        for (int i = 0; i < kLoads; i++) {
+            const int k = first + lane + i * kWave;
+            if (k >= 0 && k < nz) prod[k] = pp[i];
+        }
+#pragma unroll
+        for (int i = 0; i < IPL; i++) {
+            const int k = lane + i * kWave;
+            if (k < nr) rend[k] = row_end_list[a0 + k] - b0;
+        }
+        wave_lds_fence();
+        for (int base = 0; base <= nr; base += kWave) {
+            const int rr = base + lane;              // row slot: rr < nr ends here, rr == nr is the trailing partial row
+            const bool valid = rr <= nr;
+            int start = 0, end = 0;
+            if (valid) {
+                start = rr == 0 ? 0 : rend[rr - 1];
+                end = rr < nr ? rend[rr] : nz;
+            }
+            const int len = end - start;
+            T s = 0;
+            if (len <= kLongRow) {
+                int k = start;
+                for (; k + 8 <= end; k += 8) {
+                    T p[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) p[u] = prod[k + u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) s += p[u];
+                }
+                for (; k < end; k++) s += prod[k];
+            }
+            unsigned long long longrows = __ballot(len > kLongRow);
+            while (longrows) {
+                const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(longrows));
+                longrows &= longrows - 1;
+                const int ls = __builtin_amdgcn_readlane(start, src), le = __builtin_amdgcn_readlane(end, src);
+                T part = 0;
+                for (int k = ls + lane; k < le; k += kWave) part += prod[k];
+                part = group_sum<kWave>(part);
+                if (lane == src) s = part;
+            }
+            if (valid) {
+                if (rr < nr) y[row_index ? row_index[a0 + rr] : a0 + rr] = s;
+                else { row_carry[t] = a1; val_carry[t] = s; }
+            }
+        }
+    };
+    if (t_begin < t_end) {
+        int ca[kLoads], cb[kLoads];
+        T va[kLoads], vb[kLoads];
+        issue_loads(t_begin, ca, va);
+        for (int t = t_begin;; t += 2 * stride) {
+            tile(t, ca, va, cb, vb);
+            if (t + stride >= t_end) break;
+            tile(t + stride, cb, vb, ca, va);
+            if (t + 2 * stride >= t_end) break;
+        }
+    }
+}
+
 // -------------------------------------------------------------- vector ops --
 
 constexpr int kNormBlocks = 1024;
@@ -1101,6 +1261,11 @@ int variant_candidates(const spmv_hip_matrix *m, int *out, int max_out)
         for (int v : {0, 1})
             if (n < max_out) out[n++] = v;
         if (m->d_tile_pat && !m->d_hot_col && m->pat_tiles * 2 >= m->ntiles && n < max_out) out[n++] = 2;
+        // persistent workgroups with each column group's hottest labels in LDS (8 or 16 waves), for the
+        // stacked matrix of "hot_columns" = 2
+        if (m->group_cpx > 0 && m->items_per_tile == 8 * kWave)
+            for (int v : {3, 4})
+                if (n < max_out) out[n++] = v;
     } else if (n < max_out) {
         out[n++] = 0;
     }
@@ -1296,7 +1461,29 @@ template <typename T> static int launch_tiles(const spmv_hip_matrix *m, const T 
         return 0;
     }
     // variant 0: loads start at the tile's first entry; 1: line-aligned non-temporal loads (MODE 2); 2: as 1,
-    // patterned tiles reading one row's column indices
+    // patterned tiles reading one row's column indices; 3, 4: as 1 with persistent workgroups of 8 / 16 waves
+    // that keep the hottest labels of their column group in LDS
+    if (m->variant == 3 || m->variant == 4) {
+        if (m->group_cpx <= 0 || m->items_per_tile != 8 * kWave) {
+            set_error("tile kernel: variant %d needs the column groups of hot_columns 2 and tiles of 512", m->variant);
+            return 1;
+        }
+        int cus = 0, dev = 0;
+        SPMV_HIP_TRY(hipGetDevice(&dev), return 1);
+        SPMV_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev), return 1);
+        const dim3 grid((unsigned)std::max(cus / 8, 1) * 8);           // one workgroup per CU, a multiple of the 8 groups
+        tile_groups tg;
+        for (int g = 0; g <= 8; g++) tg.first_tile[g] = m->group_first_tile[g];
+        if (m->variant == 3)
+            hipLaunchKernelGGL((wave_tile_hot_kernel<T, 8, 8>), grid, dim3(kWave * 8), 0, st, list, index, m->d_tile_coord,
+                               m->d_col, va, x, y, m->d_row_carry, vc, tg, m->group_cpx, (int)m->stored);
+        else
+            hipLaunchKernelGGL((wave_tile_hot_kernel<T, 8, 16>), grid, dim3(kWave * 16), 0, st, list, index, m->d_tile_coord,
+                               m->d_col, va, x, y, m->d_row_carry, vc, tg, m->group_cpx, (int)m->stored);
+        hipLaunchKernelGGL((tile_fixup_kernel<T>), dim3(cdiv(m->ntiles, kBlock)), dim3(kBlock), 0, st, m->ntiles,
+                           list_len, index, m->d_row_carry, vc, y);
+        return 0;
+    }
     if (m->variant < 0 || m->variant > 2) { set_error("tile kernel: unknown kernel variant %d", m->variant); return 1; }
     if (m->variant == 2 && !m->d_tile_pat) { set_error("tile kernel: variant 2 needs the tile patterns"); return 1; }
     const unsigned char *pat = m->variant == 2 ? m->d_tile_pat : nullptr;
@@ -1356,20 +1543,43 @@ __global__ __launch_bounds__(kBlock) void permute_x_kernel(int n, const int *__r
     xh[k] = old >= 0 ? x[old] : (T)0;             // labels without a column (dealing over the XCDs leaves up to 7)
 }
 
+// presence[r]: bit g set when group g's virtual row of r (g * rows + r) holds entries
+__global__ __launch_bounds__(kBlock) void group_presence_kernel(int rows, const int *__restrict__ vrow_ptr,
+                                                                unsigned char *__restrict__ presence)
+{
+    int r = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (r >= rows) return;
+    unsigned bits = 0;
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+        const size_t v = (size_t)g * rows + r;
+        bits |= (vrow_ptr[v + 1] > vrow_ptr[v] ? 1u : 0u) << g;
+    }
+    presence[r] = (unsigned char)bits;
+}
+
+int launch_group_presence(int rows, const int *d_vrow_ptr, unsigned char *d_presence, hipStream_t stream)
+{
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(group_presence_kernel, dim3((unsigned)((rows + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, rows,
+                       d_vrow_ptr, d_presence);
+    SPMV_HIP_TRY(hipGetLastError(), return 1);
+    return 0;
+}
+
 // y[r] = the partial results of row r in group order; a group without entries in the row left
-// its slot unwritten and is skipped (its virtual row is empty)
+// its slot unwritten and is skipped (one presence byte per row says which)
 template <typename T>
-__global__ __launch_bounds__(kBlock) void sum_partials_kernel(int rows, const int *__restrict__ vrow_ptr,
+__global__ __launch_bounds__(kBlock) void sum_partials_kernel(int rows, const unsigned char *__restrict__ presence,
                                                               const T *__restrict__ part, T *__restrict__ y)
 {
     int r = (int)(blockIdx.x * kBlock + threadIdx.x);
     if (r >= rows) return;
+    const unsigned bits = presence[r];
     T p[8];
 #pragma unroll
-    for (int g = 0; g < 8; g++) {
-        const size_t v = (size_t)g * rows + r;
-        p[g] = vrow_ptr[v + 1] > vrow_ptr[v] ? __builtin_nontemporal_load(part + v) : (T)0;
-    }
+    for (int g = 0; g < 8; g++)
+        p[g] = (bits >> g) & 1u ? __builtin_nontemporal_load(part + (size_t)g * rows + r) : (T)0;
     T s = p[0];
 #pragma unroll
     for (int g = 1; g < 8; g++) s += p[g];
@@ -1384,7 +1594,7 @@ static int launch_mult_xcd(const spmv_hip_matrix *m, const T *x, T *y, hipStream
                        (T *)m->d_hot_x);
     if (launch_mult(m->xcd_sub, m->d_hot_x, m->d_xcd_y, st)) return 1;
     hipLaunchKernelGGL((sum_partials_kernel<T>), dim3(cdiv(m->rows, kBlock)), dim3(kBlock), 0, st, m->rows,
-                       m->xcd_sub->d_row_ptr, (const T *)m->d_xcd_y, y);
+                       m->d_xcd_presence, (const T *)m->d_xcd_y, y);
     SPMV_HIP_TRY(hipGetLastError(), return 1);
     return 0;
 }

@@ -190,6 +190,9 @@ def test_c3_rmat_scale26_against_the_oracle(orc):
         if fmt == S.CSR_BAL:                                           # ... and dealt over the XCDs (537 M virtual rows)
             m.set_option("hot_columns", 2)
             _check_reassociated(orc, _mult(m, x, rows), want, bound, ("csr_bal", "hot_columns 2"))
+            for hv in (3, 4):                                          # each group's hottest labels of x in LDS
+                m.set_option("hot_variant", hv)
+                _check_reassociated(orc, _mult(m, x, rows), want, bound, ("csr_bal", "hot_columns 2", "tile kernel", hv))
         m.free()
         del y
         torch.cuda.empty_cache()

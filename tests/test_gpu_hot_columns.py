@@ -73,10 +73,20 @@ def test_hot_columns_product_is_bit_identical(orc, name):
             if dt == S.F64:
                 mag = orc.mult_csr_base(rp, cj, np.abs(va), np.abs(x))
                 assert np.all(np.abs(split - want) <= 1e-12 * mag + 1e-300)
+            # the tile kernels of the stacked matrix: 3 and 4 keep each column group's hottest labels in LDS
+            # and otherwise are kernel 1, bit for bit
+            m.set_option("hot_variant", 1)
+            tiles = m.mult(x)
+            assert orc.rel_l2(tiles, plain) <= (1e-13 if dt == S.F64 else 2e-6)
+            for hv in (3, 4):
+                m.set_option("hot_variant", hv)
+                assert bits_equal(m.mult(x), tiles), (name, fmt, dt, hv)
             m.analyze(1)
             assert orc.rel_l2(m.mult(x), plain) <= (1e-13 if dt == S.F64 else 2e-6)
             m.set_option("hot_columns", 0)
             assert m.info.hot_columns == 0 and m.info.device_bytes == bytes_plain
+            with pytest.raises(S.SpmvHipError, match="hot_columns 2"):
+                m.set_option("hot_variant", 3)
             m.free()
 
 
@@ -113,4 +123,26 @@ def test_auto_may_relabel_the_columns_of_a_graph_matrix(orc):
     assert m.info.hot_columns == 0 or m.info.format in (S.CSR_SCALAR, S.CSR_VECTOR, S.CSR_MERGE, S.CSR_BAL)
     assert orc.rel_l2(m.mult(x), orc.mult_csr_base(rp, cj, va, x)) <= 1e-13
     print("auto on rmat20:", S.FORMAT_NAMES[m.info.format], "variant", m.info.variant, "hot_columns", m.info.hot_columns)
+    m.free()
+
+
+@pytest.mark.parametrize("dt", [S.F64, S.F32])
+def test_hot_labels_in_lds_on_a_graph_matrix(orc, dt):
+    """R-MAT scale 18 (x of 2 MiB, 32768 labels per column group, more than the LDS holds): the persistent
+    tile kernels read part of x from LDS and the rest from memory, and give the bits of the plain tile
+    kernel; against the oracle by the tolerance of the eight partial sums."""
+    rows, cols, rp, cj, va = G.rmat(18, 16, seed=5)
+    rp, cj, va = _np(rp, np.int32), _np(cj, np.int32), _np(va, np.float64)
+    coo = S.make_coo(np.repeat(np.arange(rows, dtype=np.int32), np.diff(rp)), cj, va)
+    x = np.random.default_rng(8).standard_normal(cols)
+    want = orc.mult_csr_base(rp, cj, va, x)
+    m = Matrix.csr_bal(rows, cols, coo, dt)
+    m.set_option("hot_columns", 2)
+    m.set_option("hot_variant", 1)
+    tiles = m.mult(x)
+    assert orc.rel_l2(tiles, want) <= (1e-13 if dt == S.F64 else 2e-6)
+    for hv in (3, 4):
+        m.set_option("hot_variant", hv)
+        for _ in range(2):                                  # the second product finds the LDS of the first one's workgroups gone
+            assert bits_equal(m.mult(x), tiles), hv
     m.free()

@@ -64,6 +64,8 @@ def main():
             m.analyze(3)
             info = m.info
             variant = f"{info.lanes_per_row} lanes, {info.variant}" if fmt == S.CSR_VECTOR else str(info.variant)
+            if info.hot_columns == 2:
+                variant += f", tiles {info.hot_variant}"
             for _ in range(3):
                 m.mult_dev(x.data_ptr(), y.data_ptr(), st)
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]

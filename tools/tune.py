@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--variants", default="0")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--hot", type=int, default=0, help="option hot_columns of CSR-based handles (0, 1, 2)")
+    ap.add_argument("--hot-variants", default="", help="with --hot 2: comma list of tile kernels of the stacked matrix (0, 1, 3, 4)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     dtype = S.F64 if args.dtype == "f64" else S.F32
@@ -62,8 +63,14 @@ def main():
                                    args.sigma if fmt in (S.SELL, S.SELL_DFC) else 0, st)
         if args.hot:
             m.set_option("hot_columns", args.hot)
-        for var in [v if v == "auto" else int(v) for v in args.variants.split(",")]:
-            if var == "auto":
+        variants = [v if v == "auto" else int(v) for v in args.variants.split(",")]
+        if args.hot_variants:
+            variants = [("hot", int(v)) for v in args.hot_variants.split(",")]
+        for var in variants:
+            if isinstance(var, tuple):
+                m.set_option("hot_variant", var[1])
+                var = 100 + var[1]
+            elif var == "auto":
                 m.analyze(3)
                 var = m.info.variant
             else:
