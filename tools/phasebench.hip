@@ -160,6 +160,63 @@ __global__ __launch_bounds__(WAVES * 64) void phased(const double *val, const in
     }
 }
 
+// writer wave: persistent workgroups of P producer waves and one writer wave.  A producer never issues a
+// global store: it parks the 64 results of a slice in one of its two LDS slots and raises the slot's
+// sequence number; the writer wave polls the slots, copies a parked slice to y and reports the slot free.
+// What this separates: on this ISA loads and stores share one in-order counter per wave, so a wave that
+// has stored cannot use the data of any later load before the store is acknowledged, and a wave that ends
+// with a store keeps its slot until then.  Here only the writer waits for write acknowledgements.
+__device__ __forceinline__ int lds_peek(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_poke(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+template <int U, bool NT, int P, bool STORE>
+__global__ __launch_bounds__((P + 1) * 64) void writer_wave(const double *val, const int *col, int nslices, int W, double *y,
+                                                            double *out)
+{
+    __shared__ double parked[P][2][64];
+    __shared__ int seq[P][2];                      // 1-based number of the producer's slice parked in the slot
+    __shared__ int taken[P];                       // slices of the producer the writer has copied out
+    if (threadIdx.x < P) { seq[threadIdx.x][0] = 0; seq[threadIdx.x][1] = 0; taken[threadIdx.x] = 0; }
+    __syncthreads();
+    const unsigned g = xcd_block(blockIdx.x, gridDim.x);
+    const int wave = threadIdx.x / 64, lane = threadIdx.x & 63;
+    const long long total = nslices;
+    const int first = (int)(total * g / gridDim.x), last = (int)(total * (g + 1) / gridDim.x);
+    if (wave < P) {
+        int q = 0;
+        for (int s = first + wave; s < last; s += P, q++) {
+            const double acc = slice_sum<U, NT>(val, col, __builtin_amdgcn_readfirstlane(s), W, lane);
+            while (lds_peek(&taken[wave]) < q - 1) __builtin_amdgcn_s_sleep(1);      // slot q & 1 held slice q - 2
+            asm volatile("" ::: "memory");
+            parked[wave][q & 1][lane] = acc;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) lds_poke(&seq[wave][q & 1], q + 1);
+        }
+    } else {
+        int copied = 0;                            // lane w: slices taken from producer w
+        int remaining = last - first;
+        while (remaining > 0) {
+            bool any = false;
+            for (int w = 0; w < P; w++) {
+                const int c = __builtin_amdgcn_readlane(copied, w);
+                if (first + w + c * P >= last) continue;
+                if (lds_peek(&seq[w][c & 1]) != c + 1) continue;
+                asm volatile("" ::: "memory");
+                const double v = parked[w][c & 1][lane];
+                const int s = first + w + c * P;
+                if (STORE) y[(size_t)s * 64 + lane] = v;
+                else if (v == 12345.678) out[0] = v;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) lds_poke(&taken[w], c + 1);
+                if (lane == w) copied++;
+                any = true;
+                remaining--;
+            }
+            if (!any) __builtin_amdgcn_s_sleep(1);
+        }
+    }
+}
+
 template <typename F> static double time_ms(F launch, int reps = 20)
 {
     hipEvent_t a, b;
@@ -185,7 +242,11 @@ int main()
     CK(hipMemset(val, 0, n * 8)); CK(hipMemset(col, 0, n * 4));
     const double gb = n * 12 / 1e9;
     unsigned g = (nslices + 3) / 4;
+    const bool writer_only = getenv("PHASEBENCH_WRITER_ONLY") != nullptr;
 #define RUN(NAME, ...) { double t = time_ms([&] { __VA_ARGS__; }); printf("%-58s %.4f ms  %.1f GB/s\n", NAME, t, gb / t * 1e3); fflush(stdout); }
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    if (!writer_only) {
     RUN("direct U9 plain nostore", hipLaunchKernelGGL((direct<9, false, false>), dim3(g), dim3(256), 0, 0, val, col, nslices, W, y, out));
     RUN("direct U9 nt    nostore", hipLaunchKernelGGL((direct<9, true, false>), dim3(g), dim3(256), 0, 0, val, col, nslices, W, y, out));
     RUN("direct U9 plain store", hipLaunchKernelGGL((direct<9, false, true>), dim3(g), dim3(256), 0, 0, val, col, nslices, W, y, out));
@@ -220,8 +281,7 @@ int main()
                                          sh.bpw, y_bytes));
         }
     }
-    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
-    const int cus = prop.multiProcessorCount;
+    }
     auto run_phased = [&](auto kernel, const char *what, int waves, int wgs_per_cu, int rounds, int sync) {
         const int G = cus * wgs_per_cu;
         const int per_wg = (nslices + G - 1) / G + 1;
@@ -239,6 +299,17 @@ int main()
         printf("%-58s %.4f ms  %.1f GB/s\n", name, t, gb / t * 1e3); fflush(stdout);
         (void)sync;
     };
+    if (getenv("PHASEBENCH_WRITER_ONLY")) {
+        RUN("direct U9 nt    nostore", hipLaunchKernelGGL((direct<9, true, false>), dim3(g), dim3(256), 0, 0, val, col, nslices, W, y, out));
+        RUN("direct U9 nt    store", hipLaunchKernelGGL((direct<9, true, true>), dim3(g), dim3(256), 0, 0, val, col, nslices, W, y, out));
+    }
+#define WRITER(P, PERCU) \
+    RUN("writer wave: " #P " producers + 1 writer, " #PERCU " wg/cu, nostore", hipLaunchKernelGGL((writer_wave<9, true, P, false>), dim3(cus * PERCU), dim3((P + 1) * 64), 0, 0, val, col, nslices, W, y, out)); \
+    RUN("writer wave: " #P " producers + 1 writer, " #PERCU " wg/cu, store", hipLaunchKernelGGL((writer_wave<9, true, P, true>), dim3(cus * PERCU), dim3((P + 1) * 64), 0, 0, val, col, nslices, W, y, out));
+    WRITER(15, 2)
+    WRITER(7, 4)
+    WRITER(3, 8)
+    WRITER(15, 1)
     RUN("direct U27 nt    nostore", hipLaunchKernelGGL((direct<27, true, false>), dim3(g), dim3(256), 0, 0, val, col, nslices, W, y, out));
     RUN("direct U27 nt    store", hipLaunchKernelGGL((direct<27, true, true>), dim3(g), dim3(256), 0, 0, val, col, nslices, W, y, out));
     return 0;
