@@ -28,4 +28,9 @@ for v in $variant $general; do
     python3 "$root/tools/record_traffic.py" --key "sell/stencil27/252/f64/gpus1/variant$v" --fetch "$out/v${v}_FETCH_SIZE" --write "$out/v${v}_WRITE_SIZE" --source "tools/profile_bench.sh $tag (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --variant $v)" > "$out/v${v}_traffic.json"
 done
 rm -rf "$out/trace" "$out"/v*_FETCH_SIZE "$out"/v*_WRITE_SIZE
+# the line as the round-end driver will see it, now with the traffic record in place
+timeout -k 10 400 python3 "$root/bench.py" > "$out/bench_final.json" 2> "$out/bench_final.err"
+tail -1 "$out/bench_final.json" > "$root/profiles/${tag}_bench_n1.json"
+# profiles/ does not travel back from a GPU box, gpurun_out/ does
+cp "$root/profiles/hbm_traffic.json" "$root/profiles/${tag}_bench_n1.json" "$root/profiles/${tag}_bench_n1_kernel_stats.csv" "$out/"
 echo "profile_bench $tag done: variant $variant, general $general"
