@@ -193,8 +193,9 @@ static int build_rowblock(spmv_hip_rowblock *rb, const int *d_row_ptr, const int
         for (int k = 0; k < 4 && ok; k++) ok = device_exclusive_scan(d_cnt[k], d_pos[k], n1, st) == 0;
         if (!ok) break;
         int totals[4];
-        for (int k = 0; k < 4 && ok; k++)
-            ok = hipMemcpy(&totals[k], d_pos[k] + rows, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+        for (int k = 0; k < 4 && ok; k++)           // on the caller's stream: a plain hipMemcpy does not wait for a non-blocking one
+            ok = hipMemcpyAsync(&totals[k], d_pos[k] + rows, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess;
+        ok = ok && hipStreamSynchronize(st) == hipSuccess;
         if (!ok) { set_error("rowblock: reading the scan totals failed"); break; }
         const int64_t nremote = totals[0];
         rb->interior_nnz = totals[1];
