@@ -60,6 +60,9 @@ static int check_dims(int rows, int columns, int64_t nnz, int dtype)
 {
     if (rows < 0 || columns < 0 || nnz < 0) { set_error("negative dimension"); return 1; }
     if (dtype != SPMV_HIP_F64 && dtype != SPMV_HIP_F32) { set_error("unknown dtype %d", dtype); return 1; }
+    // entry positions are 32-bit (as the reference's int nnz and row pointers); the chunked kernels add up to
+    // 2048 to a position before clamping it into the row block's run
+    if (nnz > 0x7fffffffLL - 4096) { set_error("%lld non-zeros exceed the 32-bit entry positions (limit 2^31 - 4096)", (long long)nnz); return 1; }
     return 0;
 }
 
