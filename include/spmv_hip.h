@@ -342,12 +342,13 @@ int spmv_hip_scale_dev(int n, const void *d_y, void *d_x, int dtype, const doubl
  *    permuted x).  0 drops the arrays again.  spmv_hip_mult_mv ignores it.
  *    = 2: the ranking is dealt over the 8 XCDs instead, and the handle keeps a
  *    second copy of the matrix split by column group (one group per XCD, so
- *    the eight L2s hold eight different sets of hot columns) plus 8 partial
- *    results per row that a last pass adds in group order: y then differs
- *    from the plain product by reassociation (tolerance parity).  Costs
- *    (4 + V) bytes per entry plus (36 + 8 V) bytes per row of HBM; pays once x
+ *    the eight L2s hold eight different sets of hot columns) plus one partial
+ *    result per row and group with entries, which a last pass adds in group
+ *    order: y then differs from the plain product by reassociation (tolerance
+ *    parity).  Costs (4 + V) bytes per entry plus about 33 bytes per row and
+ *    (8 + V) bytes per row and group with entries of HBM; pays once x
  *    is far larger than the eight L2s together (R-MAT scale 26: 20.1 ms
- *    plain, 12.0 ms with 1, 8.7 ms with 2).
+ *    plain, 12.0 ms with 1, 7.4 ms with 2).
  *  "hot_variant" = tile kernel of that second copy (needs "hot_columns" = 2;
  *    spmv_hip_analyze picks it by trial): 0, 1 = the balanced-CSR kernels, one
  *    workgroup per tile; 3, 4 = persistent workgroups of 8 / 16 waves, one per

@@ -478,7 +478,7 @@ int spmv_hip_free(spmv_hip_matrix *m)
     release_csr(m);
     void *ptrs[] = {m->d_tile_coord, m->d_row_carry, m->d_val_carry, m->d_nzr_id, m->d_nzr_end, m->d_slice_ptr,
                     m->d_row_order, m->d_slice_ident, m->d_scol, m->d_sval, m->d_sorted_len, m->d_vop_ptr, m->d_vop_len,
-                    m->d_x, m->d_y, m->d_norm, m->d_hot_col, m->d_hot_old, m->d_hot_x, m->d_xcd_y, m->d_xcd_presence, m->d_sdiag, m->d_block_pat, m->d_tile_pat};
+                    m->d_x, m->d_y, m->d_norm, m->d_hot_col, m->d_hot_old, m->d_hot_x, m->d_xcd_y, m->d_xcd_presence, m->d_xcd_base, m->d_sdiag, m->d_block_pat, m->d_tile_pat};
     if (m->xcd_sub) spmv_hip_free(m->xcd_sub);
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -547,9 +547,9 @@ static void drop_hot_columns(spmv_hip_matrix *m)
         m->xcd_bytes = 0;
         spmv_hip_free(m->xcd_sub);
         (void)hipFree(m->d_hot_old); (void)hipFree(m->d_hot_x); (void)hipFree(m->d_xcd_y);
-        (void)hipFree(m->d_xcd_presence);
-        m->xcd_sub = nullptr; m->d_hot_old = nullptr; m->d_hot_x = nullptr; m->d_xcd_y = nullptr; m->xcd_cpx = 0;
-        m->d_xcd_presence = nullptr;
+        (void)hipFree(m->d_xcd_presence); (void)hipFree(m->d_xcd_base);
+        m->xcd_sub = nullptr; m->d_hot_old = nullptr; m->d_hot_x = nullptr; m->d_xcd_y = nullptr; m->xcd_cpx = 0; m->xcd_used_cpx = 0;
+        m->d_xcd_presence = nullptr; m->d_xcd_base = nullptr;
         return;
     }
     if (!m->d_hot_col) return;
@@ -562,13 +562,14 @@ static void drop_hot_columns(spmv_hip_matrix *m)
 static int build_xcd_split(spmv_hip_matrix *m, hipStream_t st)
 {
     if (m->d_row_map) { set_error("hot_columns 2 does not combine with a row map"); return 1; }
-    int *vrp = nullptr, *vcol = nullptr, *old_of_label = nullptr, cpx = 0;
+    int *vrp = nullptr, *vcol = nullptr, *old_of_label = nullptr, cpx = 0, used_cpx = 0;
     void *vval = nullptr;
-    if (build_xcd_columns(m, m->dtype == SPMV_HIP_F64, st, &vrp, &vcol, &vval, &old_of_label, &cpx)) return 1;
+    if (build_xcd_columns(m, m->dtype == SPMV_HIP_F64, st, &vrp, &vcol, &vval, &old_of_label, &cpx, &used_cpx)) return 1;
     const int64_t es = (int64_t)dtype_size(m->dtype), labels = 8 * (int64_t)cpx;
     spmv_hip_matrix *sub = new_handle(SPMV_HIP_CSR_BAL, m->dtype, 8 * m->rows, (int)labels, m->nnz);
     void *xh = nullptr, *yp = nullptr;
     unsigned char *presence = nullptr;
+    int *base_count = nullptr, *base = nullptr;
     int rc = 1;
     do {
         if (!sub) break;
@@ -596,19 +597,28 @@ static int build_xcd_split(spmv_hip_matrix *m, hipStream_t st)
             }
         }
         SPMV_HIP_TRY(hipMalloc(&xh, (size_t)(labels * es)), break);
-        SPMV_HIP_TRY(hipMalloc(&yp, (size_t)(8 * (int64_t)m->rows * es)), break);
+        SPMV_HIP_TRY(hipMemsetAsync(xh, 0, (size_t)(labels * es), st), break);     // labels no entry names keep this zero
+        // the partial results stay packed, one slot per non-empty virtual row
+        sub->packed_rows = true;
+        SPMV_HIP_TRY(hipMalloc(&yp, (size_t)std::max<int64_t>(sub->nz_rows, 1) * es), break);
         SPMV_HIP_TRY(hipMalloc((void **)&presence, (size_t)m->rows), break);
+        const size_t nbase = 8 * (((size_t)m->rows + kWave - 1) / kWave) + 1;
+        SPMV_HIP_TRY(hipMalloc((void **)&base_count, nbase * sizeof(int)), break);
+        SPMV_HIP_TRY(hipMalloc((void **)&base, nbase * sizeof(int)), break);
         if (launch_group_presence(m->rows, sub->d_row_ptr, presence, st)) break;
+        SPMV_HIP_TRY(hipMemsetAsync(base_count, 0, nbase * sizeof(int), st), break);
+        if (launch_group_block_count(m->rows, presence, base_count, st)) break;
+        if (device_exclusive_scan(base_count, base, nbase, st)) break;
         SPMV_HIP_TRY(hipStreamSynchronize(st), break);
-        m->xcd_sub = sub; m->xcd_cpx = cpx;
-        m->d_hot_old = old_of_label; m->d_hot_x = xh; m->d_xcd_y = yp; m->d_xcd_presence = presence;
-        m->xcd_bytes = sub->device_bytes + labels * (4 + es) + 8 * (int64_t)m->rows * es + m->rows;
+        m->xcd_sub = sub; m->xcd_cpx = cpx; m->xcd_used_cpx = used_cpx;
+        m->d_hot_old = old_of_label; m->d_hot_x = xh; m->d_xcd_y = yp; m->d_xcd_presence = presence; m->d_xcd_base = base;
+        m->xcd_bytes = sub->device_bytes + labels * (4 + es) + (int64_t)sub->nz_rows * es + m->rows + (int64_t)(nbase * sizeof(int));
         m->device_bytes += m->xcd_bytes;
-        sub = nullptr; old_of_label = nullptr; xh = nullptr; yp = nullptr; presence = nullptr;
+        sub = nullptr; old_of_label = nullptr; xh = nullptr; yp = nullptr; presence = nullptr; base = nullptr;
         rc = 0;
     } while (0);
     if (sub) spmv_hip_free(sub);
-    void *scratch[] = {vrp, vcol, vval, old_of_label, xh, yp, presence};
+    void *scratch[] = {vrp, vcol, vval, old_of_label, xh, yp, presence, base_count, base};
     for (void *p : scratch)
         if (p) (void)hipFree(p);
     return rc;

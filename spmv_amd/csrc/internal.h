@@ -85,6 +85,7 @@ struct spmv_hip_matrix {
     int *d_nzr_id = nullptr;       // [nz_rows] original row index
     int *d_nzr_end = nullptr;      // [nz_rows] row end offsets (row_ptr[row+1])
     bool has_empty_rows = false;
+    bool packed_rows = false;       // balanced CSR: y[k] belongs to the k-th non-empty row (the caller unpacks)
     bool leave_empty_rows = false;  // balanced CSR: y of empty rows is left alone (the caller skips them)
 
     // sliced formats (SELL-C-sigma, SELLP, ELL)
@@ -119,7 +120,9 @@ struct spmv_hip_matrix {
     int group_first_tile[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     void *d_xcd_y = nullptr;
     unsigned char *d_xcd_presence = nullptr;        // per row: bit g set when column group g has entries in the row
+    int *d_xcd_base = nullptr;                      // [8 * ceil(rows / 64)] slot of each 64-row block's first partial result per group
     int xcd_cpx = 0;
+    int xcd_used_cpx = 0;           // labels per group that the matrix references (the rest of a group never needs x)
     int64_t xcd_bytes = 0;          // what the stacked handle and its vectors added to device_bytes
 
     // staging vectors for the host-pointer multiply and the bench loop
@@ -154,9 +157,10 @@ spmv_hip_matrix *adopt_device_csr(int format, int rows, int columns, int64_t nnz
 // creator hands over dtype elements).
 int choose_lanes_per_row(int rows, int64_t stored);
 int launch_group_presence(int rows, const int *d_vrow_ptr, unsigned char *d_presence, hipStream_t stream);   // kernels.hip
+int launch_group_block_count(int rows, const unsigned char *d_presence, int *d_count, hipStream_t stream);
 int build_hot_columns(spmv_hip_matrix *m, hipStream_t stream);                            // sort.hip
 int build_xcd_columns(const spmv_hip_matrix *m, bool val_is_f64, hipStream_t stream, int **vrow_ptr, int **vcol,
-                      void **vval, int **old_of_label, int *cpx);                         // sort.hip
+                      void **vval, int **old_of_label, int *cpx, int *used_cpx);                         // sort.hip
 int device_exclusive_scan(const int *d_in, int *d_out, size_t n, hipStream_t stream);   // sort.hip (rocPRIM)
 int device_coo_to_csr(int rows, int columns, int64_t nnz, struct mtx *coo, bool values_f64, int **d_row_ptr,
                       int **d_col, void **d_val);                                         // sort.hip

@@ -1451,7 +1451,8 @@ template <typename T> static int launch_tiles(const spmv_hip_matrix *m, const T 
     const bool bal = m->format == SPMV_HIP_CSR_BAL;
     const int list_len = bal ? m->nz_rows : m->rows;
     const int *list = bal ? m->d_nzr_end : m->d_row_ptr + 1;
-    const int *index = bal ? m->d_nzr_id : nullptr;
+    // packed_rows: results go to the position in the non-empty row list instead of the row itself
+    const int *index = bal && !m->packed_rows ? m->d_nzr_id : nullptr;
     const T *va = (const T *)m->d_val;
     T *vc = (T *)m->d_val_carry;
     if (bal && m->has_empty_rows && !m->leave_empty_rows)
@@ -1543,6 +1544,18 @@ __global__ __launch_bounds__(kBlock) void permute_x_kernel(int n, const int *__r
     xh[k] = old >= 0 ? x[old] : (T)0;             // labels without a column (dealing over the XCDs leaves up to 7)
 }
 
+// the same for the labels dealt over column groups: group blockIdx.y, its first `used` labels
+template <typename T>
+__global__ __launch_bounds__(kBlock) void permute_x_groups_kernel(int used, int cpx, const int *__restrict__ old_of_new,
+                                                                  const T *__restrict__ x, T *__restrict__ xh)
+{
+    const int k = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (k >= used) return;
+    const size_t label = (size_t)blockIdx.y * cpx + k;
+    const int old = old_of_new[label];
+    xh[label] = old >= 0 ? x[old] : (T)0;
+}
+
 // presence[r]: bit g set when group g's virtual row of r (g * rows + r) holds entries
 __global__ __launch_bounds__(kBlock) void group_presence_kernel(int rows, const int *__restrict__ vrow_ptr,
                                                                 unsigned char *__restrict__ presence)
@@ -1567,34 +1580,69 @@ int launch_group_presence(int rows, const int *d_vrow_ptr, unsigned char *d_pres
     return 0;
 }
 
-// y[r] = the partial results of row r in group order; a group without entries in the row left
-// its slot unwritten and is skipped (one presence byte per row says which)
-template <typename T>
-__global__ __launch_bounds__(kBlock) void sum_partials_kernel(int rows, const unsigned char *__restrict__ presence,
-                                                              const T *__restrict__ part, T *__restrict__ y)
+// count[g * nblk + b] = rows of the 64-row block b with entries in column group g: after an exclusive scan,
+// the position of the block's first such row among the non-empty virtual rows (which the stacked matrix
+// lists group by group, rows ascending)
+__global__ __launch_bounds__(kBlock) void group_block_count_kernel(int rows, int nblk, const unsigned char *__restrict__ presence,
+                                                                   int *__restrict__ count)
 {
-    int r = (int)(blockIdx.x * kBlock + threadIdx.x);
-    if (r >= rows) return;
-    const unsigned bits = presence[r];
+    const int r = (int)(blockIdx.x * kBlock + threadIdx.x);
+    const unsigned bits = r < rows ? presence[r] : 0u;
+    const int blk = r >> 6;
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+        const unsigned long long mask = __ballot((bits >> g) & 1u);
+        if ((threadIdx.x & 63) == 0 && blk < nblk) count[(size_t)g * nblk + blk] = __popcll(mask);
+    }
+}
+
+int launch_group_block_count(int rows, const unsigned char *d_presence, int *d_count, hipStream_t stream)
+{
+    if (rows <= 0) return 0;
+    const int nblk = (rows + kWave - 1) / kWave;
+    hipLaunchKernelGGL(group_block_count_kernel, dim3((unsigned)((rows + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, rows,
+                       nblk, d_presence, d_count);
+    SPMV_HIP_TRY(hipGetLastError(), return 1);
+    return 0;
+}
+
+// y[r] = the partial results of row r in group order.  The tile kernel left them packed: one slot per
+// non-empty virtual row, in the stacked matrix's order, so that they are written and read as dense
+// streams.  Row r's slot for group g is base[g][r / 64] + the number of rows before r in its 64-row
+// block that have entries in g (a ballot over the wave's presence bits).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sum_partials_kernel(int rows, int nblk, const unsigned char *__restrict__ presence,
+                                                              const int *__restrict__ base, const T *__restrict__ part,
+                                                              T *__restrict__ y)
+{
+    const int r = (int)(blockIdx.x * kBlock + threadIdx.x);
+    const unsigned bits = r < rows ? presence[r] : 0u;
+    const int blk = __builtin_amdgcn_readfirstlane(r >> 6);
+    const unsigned long long before = (1ull << (threadIdx.x & 63)) - 1ull;
     T p[8];
 #pragma unroll
-    for (int g = 0; g < 8; g++)
-        p[g] = (bits >> g) & 1u ? __builtin_nontemporal_load(part + (size_t)g * rows + r) : (T)0;
+    for (int g = 0; g < 8; g++) {
+        const bool has = (bits >> g) & 1u;
+        const unsigned long long mask = __ballot(has);
+        p[g] = 0;
+        if (has) p[g] = __builtin_nontemporal_load(part + base[(size_t)g * nblk + blk] + __popcll(mask & before));
+    }
     T s = p[0];
 #pragma unroll
     for (int g = 1; g < 8; g++) s += p[g];
-    y[r] = s;
+    if (r < rows) y[r] = s;
 }
 
 template <typename T>
 static int launch_mult_xcd(const spmv_hip_matrix *m, const T *x, T *y, hipStream_t st)
 {
-    const int labels = 8 * m->xcd_cpx;
-    hipLaunchKernelGGL((permute_x_kernel<T>), dim3(cdiv(labels, kBlock)), dim3(kBlock), 0, st, labels, m->d_hot_old, x,
-                       (T *)m->d_hot_x);
+    // only the labels the matrix references: the first xcd_used_cpx of each group
+    if (m->xcd_used_cpx > 0)
+        hipLaunchKernelGGL((permute_x_groups_kernel<T>), dim3(cdiv(m->xcd_used_cpx, kBlock), 8), dim3(kBlock), 0, st,
+                           m->xcd_used_cpx, m->xcd_cpx, m->d_hot_old, x, (T *)m->d_hot_x);
     if (launch_mult(m->xcd_sub, m->d_hot_x, m->d_xcd_y, st)) return 1;
     hipLaunchKernelGGL((sum_partials_kernel<T>), dim3(cdiv(m->rows, kBlock)), dim3(kBlock), 0, st, m->rows,
-                       m->d_xcd_presence, (const T *)m->d_xcd_y, y);
+                       (m->rows + kWave - 1) / kWave, m->d_xcd_presence, m->d_xcd_base, (const T *)m->d_xcd_y, y);
     SPMV_HIP_TRY(hipGetLastError(), return 1);
     return 0;
 }

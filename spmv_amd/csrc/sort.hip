@@ -280,8 +280,8 @@ int build_hot_columns(spmv_hip_matrix *m, hipStream_t st)
 // ---- the same, with the columns dealt over the eight XCDs ----
 //
 // With one ranking for the whole chip every XCD's L2 ends up holding the same hottest columns.  Here
-// the ranking is dealt over eight groups in runs of 16 columns (group g owns the labels g*cpx ..
-// g*cpx+cpx-1, cpx = columns/8 rounded up to whole runs),
+// the ranking is dealt over eight groups -- the first 65536 ranks one at a time, the rest in runs of
+// 16 columns (group g owns the labels g*cpx .. g*cpx+cpx-1, cpx = columns/8 rounded up to whole runs),
 // so each group owns a contiguous range of the permuted x with an equal share of the references and
 // its own hottest columns in front; the matrix is split by group into eight row-aligned pieces that
 // are stacked into one CSR of 8*rows "virtual" rows (piece g holds virtual rows g*rows..g*rows+rows-1).
@@ -292,15 +292,27 @@ int build_hot_columns(spmv_hip_matrix *m, hipStream_t st)
 
 constexpr int kXcds = 8;
 
-__global__ void xcd_label_kernel(int cols, int cpx, const int *__restrict__ old_of_rank,
+__global__ void xcd_label_kernel(int cols, int cpx, int snake, const int *__restrict__ old_of_rank,
                                  int *__restrict__ label_of_old, int *__restrict__ old_of_label)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= cols) return;
-    // ranks are dealt in runs of 16 (one 128-byte line of doubles), so that columns which were
-    // neighbours in x and stayed neighbours in the ranking (equal counts) still share a line
-    const int run = k / 16, g = run % kXcds;
-    const int label = g * cpx + (run / kXcds) * 16 + k % 16;
+    int g, pos;
+    if (k < snake) {
+        // the hottest ranks one at a time, back and forth over the groups (0..7, 7..0, ...): a run of 16 of
+        // them would hand one group several per cent more references than the others, and the groups
+        // run side by side, one per XCD
+        const int round = k / kXcds, at = k % kXcds;
+        g = round & 1 ? kXcds - 1 - at : at;
+        pos = round;
+    } else {
+        // the rest in runs of 16 (one 128-byte line of doubles), so that columns which were neighbours in
+        // x and stayed neighbours in the ranking (equal counts) still share a line
+        const int rest = k - snake, run = rest / 16;
+        g = run % kXcds;
+        pos = snake / kXcds + (run / kXcds) * 16 + rest % 16;
+    }
+    const int label = g * cpx + pos;
     const int old = old_of_rank[k];
     label_of_old[old] = label;
     old_of_label[label] = old;
@@ -344,7 +356,7 @@ __global__ __launch_bounds__(256) void xcd_fill_kernel(int rows, int cpx, const 
 // pointers [8*rows+1], relabeled columns and values [stored], and the column of x behind every label
 // [8*cpx], -1 for the few unused labels.  0 on success.
 int build_xcd_columns(const spmv_hip_matrix *m, bool val_is_f64, hipStream_t st, int **out_vrp, int **out_vcol,
-                      void **out_vval, int **out_old_of_label, int *out_cpx)
+                      void **out_vval, int **out_old_of_label, int *out_cpx, int *out_used_cpx)
 {
     const int cols = m->columns, rows = m->rows;
     const int64_t n = m->stored;
@@ -352,6 +364,8 @@ int build_xcd_columns(const spmv_hip_matrix *m, bool val_is_f64, hipStream_t st,
     if ((int64_t)rows * kXcds > 0x7fffffffLL - 1) { set_error("hot_columns 2: %d rows x 8 exceed 32-bit row numbers", rows); return 1; }
     const int cpx = (int)(((int64_t)cols + 16 * kXcds - 1) / (16 * kXcds)) * 16;
     const size_t c = (size_t)cols, vrows = (size_t)rows * kXcds, labels = (size_t)cpx * kXcds;
+    // ranks dealt one at a time: 8192 per group (what a CU's LDS holds beside 16 waves of tile staging), whole lines
+    const int snake = std::min(65536, cols / (16 * kXcds) * (16 * kXcds));
     unsigned *d_count[2] = {nullptr, nullptr};
     int *d_id = nullptr, *d_rank_old = nullptr, *d_label_of_old = nullptr, *d_cnt = nullptr;
     void *d_temp = nullptr;
@@ -378,8 +392,29 @@ int build_xcd_columns(const spmv_hip_matrix *m, bool val_is_f64, hipStream_t st,
         SPMV_HIP_TRY(rocprim::radix_sort_pairs_desc(nullptr, temp_bytes, d_count[0], d_count[1], d_id, d_rank_old, c, 0, 32, st), break);
         SPMV_HIP_TRY(hipMalloc(&d_temp, std::max<size_t>(temp_bytes, 16)), break);
         SPMV_HIP_TRY(rocprim::radix_sort_pairs_desc(d_temp, temp_bytes, d_count[0], d_count[1], d_id, d_rank_old, c, 0, 32, st), break);
+        // how many columns the matrix references at all: the sorted counts end in zeros, and the labels of
+        // those columns (the tail of every group) never need a value of x
+        size_t referenced = 0;
+        {
+            size_t lo = 0, hi = c;
+            bool ok = true;
+            while (lo < hi && ok) {
+                const size_t mid = (lo + hi) / 2;
+                unsigned v = 0;
+                ok = hipMemcpyAsync(&v, d_count[1] + mid, sizeof v, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                     hipStreamSynchronize(st) == hipSuccess;
+                if (v > 0) lo = mid + 1; else hi = mid;
+            }
+            if (!ok) { set_error("hot_columns 2: reading the sorted counts failed"); break; }
+            referenced = lo;
+        }
+        // positions in use per group: the snake part holds 8 ranks per position, the rest 128 per 16 positions
+        if (referenced <= (size_t)snake)
+            *out_used_cpx = (int)((referenced + kXcds - 1) / kXcds);
+        else
+            *out_used_cpx = (int)std::min<size_t>(snake / kXcds + ((referenced - snake + 16 * kXcds - 1) / (16 * kXcds)) * 16, (size_t)cpx);
         SPMV_HIP_TRY(hipMemsetAsync(old_of_label, 0xFF, labels * sizeof(int), st), break);
-        hipLaunchKernelGGL(xcd_label_kernel, gcol, block, 0, st, cols, cpx, d_rank_old, d_label_of_old, old_of_label);
+        hipLaunchKernelGGL(xcd_label_kernel, gcol, block, 0, st, cols, cpx, snake, d_rank_old, d_label_of_old, old_of_label);
         hipLaunchKernelGGL(xcd_count_kernel, grow, block, 0, st, rows, cpx, m->d_row_ptr, m->d_col, d_label_of_old, d_cnt);
         SPMV_HIP_TRY(hipMemsetAsync(d_cnt + vrows, 0, sizeof(int), st), break);
         SPMV_HIP_TRY(hipGetLastError(), break);
