@@ -126,7 +126,8 @@ spmv_hip_matrix *spmv_hip_create_csr(int rows, int columns, int nnz, int alignme
                                      struct mtx *coo, int dtype, int kernel, int lanes_per_row);
 /* create_csr_merge (spmv.h:98, csr_merge.c:87-115).  The reference freezes
  * nthreads at create time (csr_merge.c:93); here the tile size plays that
- * role: items_per_tile 0 = default. */
+ * role: items_per_tile 0 = default (512; 1024 for fp32 matrices of 2^25 entries
+ * and more), else one of 256, 512, 1024, 2048. */
 spmv_hip_matrix *spmv_hip_create_csr_merge(int rows, int columns, int nnz, struct mtx *coo,
                                            int dtype, int items_per_tile);
 /* create_csr_bal (spmv.h:118, csr_bal.c:66-94): equal-nnz chunks, one per
