@@ -237,12 +237,19 @@ int main()
     const int W = 27, nslices = 250047;
     const size_t n = (size_t)nslices * W * 64;
     double *val, *y, *out; int *col; unsigned *counter;
-    CK(hipMalloc(&val, n * 8)); CK(hipMalloc(&col, n * 4)); CK(hipMalloc(&out, 8)); CK(hipMalloc(&counter, 256));
-    CK(hipMalloc(&y, (size_t)nslices * 64 * 8));
+    CK(hipMalloc(&out, 8)); CK(hipMalloc(&counter, 256));
+    if (getenv("PHASEBENCH_CONTIG")) {               // every array physically contiguous (or uncached: PHASEBENCH_CONTIG=2)
+        const unsigned fl = atoi(getenv("PHASEBENCH_CONTIG")) == 2 ? hipDeviceMallocUncached : hipDeviceMallocContiguous;
+        CK(hipExtMallocWithFlags((void **)&val, n * 8, fl)); CK(hipExtMallocWithFlags((void **)&col, n * 4, fl));
+        CK(hipExtMallocWithFlags((void **)&y, (size_t)nslices * 64 * 8, fl));
+    } else {
+        CK(hipMalloc(&val, n * 8)); CK(hipMalloc(&col, n * 4));
+        CK(hipMalloc(&y, (size_t)nslices * 64 * 8));
+    }
     CK(hipMemset(val, 0, n * 8)); CK(hipMemset(col, 0, n * 4));
     const double gb = n * 12 / 1e9;
     unsigned g = (nslices + 3) / 4;
-    const bool writer_only = getenv("PHASEBENCH_WRITER_ONLY") != nullptr;
+    const bool writer_only = getenv("PHASEBENCH_WRITER_ONLY") != nullptr || getenv("PHASEBENCH_YTYPES") != nullptr;
 #define RUN(NAME, ...) { double t = time_ms([&] { __VA_ARGS__; }); printf("%-58s %.4f ms  %.1f GB/s\n", NAME, t, gb / t * 1e3); fflush(stdout); }
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
@@ -299,6 +306,25 @@ int main()
         printf("%-58s %.4f ms  %.1f GB/s\n", name, t, gb / t * 1e3); fflush(stdout);
         (void)sync;
     };
+    if (getenv("PHASEBENCH_YTYPES")) {
+        // the same store into y allocated in other ways
+        struct { const char *name; unsigned flags; } kinds[] = {{"hipMalloc", 0xffffffffu}, {"fine-grained", hipDeviceMallocFinegrained},
+                                                                {"uncached", hipDeviceMallocUncached}, {"contiguous", hipDeviceMallocContiguous}};
+        for (auto k : kinds) {
+            double *yy = nullptr;
+            hipError_t e = k.flags == 0xffffffffu ? hipMalloc(&yy, (size_t)nslices * 512) : hipExtMallocWithFlags((void **)&yy, (size_t)nslices * 512, k.flags);
+            if (e != hipSuccess) { printf("y %s: allocation failed (%s)\n", k.name, hipGetErrorString(e)); (void)hipGetLastError(); continue; }
+            char name[96]; snprintf(name, sizeof name, "direct U9 nt store, y %s", k.name);
+            RUN(name, hipLaunchKernelGGL((direct<9, true, true>), dim3(g), dim3(256), 0, 0, val, col, nslices, W, yy, out));
+            CK(hipFree(yy));
+        }
+        double *yh = nullptr;
+        if (hipHostMalloc((void **)&yh, (size_t)nslices * 512, hipHostMallocMapped) == hipSuccess) {
+            RUN("direct U9 nt store, y in pinned host memory", hipLaunchKernelGGL((direct<9, true, true>), dim3(g), dim3(256), 0, 0, val, col, nslices, W, yh, out));
+            CK(hipHostFree(yh));
+        }
+        return 0;
+    }
     if (getenv("PHASEBENCH_WRITER_ONLY")) {
         RUN("direct U9 nt    nostore", hipLaunchKernelGGL((direct<9, true, false>), dim3(g), dim3(256), 0, 0, val, col, nslices, W, y, out));
         RUN("direct U9 nt    store", hipLaunchKernelGGL((direct<9, true, true>), dim3(g), dim3(256), 0, 0, val, col, nslices, W, y, out));
