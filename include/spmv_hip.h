@@ -151,7 +151,9 @@ spmv_hip_matrix *spmv_hip_create_sellp(int rows, int columns, int nnz, const int
 /* create_sell (spmv.h:233, sell.c:8-33) with the struct csr flattened.
  * C 0 = 64 (sell.c:5); sigma 0 = 16384 (sell.c:4).  sigma must be a multiple
  * of C (otherwise the reference's "first row of the slice is the longest"
- * rule, sellcs_format.c:152-158, does not hold) and at most 32768. */
+ * rule, sellcs_format.c:152-158, does not hold); windows of up to 32768 rows
+ * are sorted in LDS, longer ones (up to one window over the whole matrix) by
+ * a radix sort on (window, length) -- the same order either way. */
 spmv_hip_matrix *spmv_hip_create_sell(int rows, int columns, int nnz, const int *row_ptr,
                                       const int *col, const double *A, int dtype, int C, int64_t sigma);
 

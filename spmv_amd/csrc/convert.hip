@@ -10,6 +10,8 @@
 #include <algorithm>
 #include <vector>
 
+#include <rocprim/device/device_radix_sort.hpp>
+
 namespace spmv {
 
 static inline unsigned cdiv64(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
@@ -260,6 +262,67 @@ __global__ __launch_bounds__(1024) void sell_window_sort_kernel(int rows, int wi
     }
 }
 
+// Windows too long for the LDS sort: one stable radix sort over all rows on the key (window, longer
+// first); ties keep their ascending row index, as in the reference's LSD radix sort.
+__global__ void sell_window_key_kernel(int rows, int64_t window, const int *__restrict__ row_ptr,
+                                       unsigned long long *__restrict__ key, int *__restrict__ id)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const unsigned len = (unsigned)(row_ptr[r + 1] - row_ptr[r]);
+    key[r] = ((unsigned long long)(r / window) << 32) | (unsigned long long)(0xFFFFFFFFu - len);
+    id[r] = r;
+}
+
+__global__ void sell_sorted_len_kernel(int rows, const int *__restrict__ row_ptr, const int *__restrict__ row_order,
+                                       int *__restrict__ sorted_len)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= rows) return;
+    const int r = row_order[k];
+    sorted_len[k] = row_ptr[r + 1] - row_ptr[r];
+}
+
+// row_order / sorted_len of the sigma-window sort for any window length
+static int sell_sort_windows(int rows, int64_t window, const int *d_row_ptr, int *d_row_order, int *d_sorted_len, hipStream_t st)
+{
+    if (window <= kMaxSigma) {
+        int padded = 1;
+        while (padded < window) padded <<= 1;
+        const size_t lds = (size_t)padded * sizeof(int);
+        SPMV_HIP_TRY(hipFuncSetAttribute((const void *)sell_window_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                     return 1);
+        hipLaunchKernelGGL(sell_window_sort_kernel, dim3(cdiv64(rows, window)), dim3(1024), lds, st, rows, (int)window, padded,
+                           d_row_ptr, d_row_order, d_sorted_len);
+        SPMV_HIP_TRY(hipGetLastError(), return 1);
+        return 0;
+    }
+    unsigned long long *key[2] = {nullptr, nullptr};
+    int *id = nullptr;
+    void *temp = nullptr;
+    int rc = 1;
+    do {
+        const size_t n = (size_t)rows;
+        SPMV_HIP_TRY(hipMalloc((void **)&key[0], n * sizeof(unsigned long long)), break);
+        SPMV_HIP_TRY(hipMalloc((void **)&key[1], n * sizeof(unsigned long long)), break);
+        SPMV_HIP_TRY(hipMalloc((void **)&id, n * sizeof(int)), break);
+        hipLaunchKernelGGL(sell_window_key_kernel, dim3(cdiv64(rows, 256)), dim3(256), 0, st, rows, window, d_row_ptr, key[0], id);
+        SPMV_HIP_TRY(hipGetLastError(), break);
+        size_t bytes = 0;
+        SPMV_HIP_TRY(rocprim::radix_sort_pairs(nullptr, bytes, key[0], key[1], id, d_row_order, n, 0, 64, st), break);
+        SPMV_HIP_TRY(hipMalloc(&temp, std::max<size_t>(bytes, 16)), break);
+        SPMV_HIP_TRY(rocprim::radix_sort_pairs(temp, bytes, key[0], key[1], id, d_row_order, n, 0, 64, st), break);
+        hipLaunchKernelGGL(sell_sorted_len_kernel, dim3(cdiv64(rows, 256)), dim3(256), 0, st, rows, d_row_ptr, d_row_order, d_sorted_len);
+        SPMV_HIP_TRY(hipGetLastError(), break);
+        SPMV_HIP_TRY(hipStreamSynchronize(st), break);
+        rc = 0;
+    } while (0);
+    void *scratch[] = {key[0], key[1], id, temp};
+    for (void *p : scratch)
+        if (p) (void)hipFree(p);
+    return rc;
+}
+
 // ident[s] = 1 when row_order maps every row of slice s to itself (one wave per slice)
 __global__ __launch_bounds__(kWave) void slice_identity_kernel(int rows, const int *__restrict__ row_order,
                                                                unsigned char *__restrict__ ident)
@@ -503,15 +566,7 @@ int build_sell_dfc(spmv_hip_matrix *m, const int *d_row_ptr, const int *d_col, c
                 set_error("sell_dfc: sigma %lld must be a multiple of C 64", (long long)m->sigma);
                 break;
             }
-            if (window > kMaxSigma) { set_error("sell_dfc: sorting window %lld exceeds %lld rows", (long long)window, (long long)kMaxSigma); break; }
-            int padded = 1;
-            while (padded < window) padded <<= 1;
-            const size_t lds = (size_t)padded * sizeof(int);
-            SPMV_HIP_TRY(hipFuncSetAttribute((const void *)sell_window_sort_kernel,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), break);
-            hipLaunchKernelGGL(sell_window_sort_kernel, dim3(cdiv64(rows, window)), dim3(1024), lds, st, rows,
-                               (int)window, padded, d_row_ptr, m->d_row_order, m->d_sorted_len);
-            SPMV_HIP_TRY(hipGetLastError(), break);
+            if (sell_sort_windows(rows, window, d_row_ptr, m->d_row_order, m->d_sorted_len, st)) break;
             if (dev_alloc<int>(nullptr, &d_width, (size_t)m->nslices) || dev_alloc<int>(nullptr, &d_entries, (size_t)m->nslices)) break;
             hipLaunchKernelGGL(dfc_slice_stats_kernel, dim3(cdiv64(m->nslices, 256)), dim3(256), 0, st, rows, m->nslices,
                                m->d_sorted_len, d_width, d_entries);
@@ -681,17 +736,9 @@ int build_sliced(spmv_hip_matrix *m, const int *d_row_ptr, const int *d_col, con
                 set_error("sell: sigma %lld must be a multiple of C %d", (long long)m->sigma, H);
                 break;
             }
-            if (window > kMaxSigma) { set_error("sell: sorting window %lld exceeds %lld rows", (long long)window, (long long)kMaxSigma); break; }
             if (dev_alloc(m, &m->d_row_order, (size_t)rows)) break;
             if (dev_alloc<int>(nullptr, &d_sorted_len, (size_t)rows)) break;
-            int padded = 1;
-            while (padded < window) padded <<= 1;
-            size_t lds = (size_t)padded * sizeof(int);
-            SPMV_HIP_TRY(hipFuncSetAttribute((const void *)sell_window_sort_kernel,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), break);
-            hipLaunchKernelGGL(sell_window_sort_kernel, dim3(cdiv64(rows, window)), dim3(1024), lds, st, rows,
-                               (int)window, padded, d_row_ptr, m->d_row_order, d_sorted_len);
-            SPMV_HIP_TRY(hipGetLastError(), break);
+            if (sell_sort_windows(rows, window, d_row_ptr, m->d_row_order, d_sorted_len, st)) break;
             // slices whose rows all stayed in place need no row_order lookup when y is stored
             if (dev_alloc(m, &m->d_slice_ident, (size_t)m->nslices)) break;
             hipLaunchKernelGGL(slice_identity_kernel, dim3((unsigned)m->nslices), dim3(kWave), 0, st, rows, m->d_row_order,

@@ -13,7 +13,7 @@ constexpr int kWave = 64;            // gfx950 wavefront
 constexpr int kBlock = 256;          // threads per workgroup for every SpMV kernel
 constexpr int kDefaultSigma = 16384; // sell.c:4
 constexpr int kDefaultC = 64;        // sell.c:5 (max_vlen), = one wave64
-constexpr int64_t kMaxSigma = 32768; // one sorting window must fit in LDS
+constexpr int64_t kMaxSigma = 32768; // longest sorting window the LDS sort takes; longer ones go through a radix sort
 
 void set_error(const char *fmt, ...);
 void clear_error();

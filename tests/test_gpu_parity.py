@@ -235,6 +235,33 @@ def test_sell_window_with_a_very_long_row(orc):
         m.free()
 
 
+def test_sell_windows_longer_than_the_lds_sort(orc):
+    """Sorting windows above 32768 rows (one window over the whole matrix included) go through a stable radix
+    sort on (window, longer first): same row_order and slices as the reference's window sort
+    (radix_sort.c:103-122, restated by the oracle), same bits in y."""
+    rng = np.random.default_rng(11)
+    n = 100_000
+    lens = rng.integers(0, 9, n)
+    lens[rng.integers(0, n, 50)] = rng.integers(40, 200, 50)       # a few long rows, ties everywhere else
+    rp = np.zeros(n + 1, np.int32)
+    rp[1:] = np.cumsum(lens)
+    cj = np.concatenate([np.sort(rng.choice(n, l, replace=False)) for l in lens]).astype(np.int32)
+    va = rng.standard_normal(len(cj))
+    x = rng.standard_normal(n)
+    want = orc.mult_csr_base(rp, cj, va, x)
+    for sigma in (65536, 1 << 20):
+        ref = orc.sell_from_csr(rp, cj, va, 64, sigma)
+        m = Matrix.sell(n, n, rp, cj, va, S.F64, 64, sigma)
+        assert bits_equal(m.download(S.ARR_ROW_ORDER), ref["row_order"])
+        assert bits_equal(m.download(S.ARR_SLICE_PTR), ref["slice_ptr"])
+        assert bits_equal(m.download(S.ARR_COL), ref["col"])
+        assert bits_equal(m.mult(x), want)
+        m.free()
+        d = Matrix.sell_dfc(n, n, rp, cj, va, S.F64, 64, sigma)
+        assert bits_equal(d.mult(x), want)
+        d.free()
+
+
 SLICED_VARIANTS = [1, 2, 3, 4, 9, 10, 11, 12]
 # lane per row, one fma per column in order, column indices of diagonal slice columns not read
 DIAG_VARIANTS = [16, 17, 18, 19, 20, 21, 22, 23]
