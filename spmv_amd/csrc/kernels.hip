@@ -1610,27 +1610,45 @@ int launch_group_block_count(int rows, const unsigned char *d_presence, int *d_c
 // non-empty virtual row, in the stacked matrix's order, so that they are written and read as dense
 // streams.  Row r's slot for group g is base[g][r / 64] + the number of rows before r in its 64-row
 // block that have entries in g (a ballot over the wave's presence bits).
+// Each wave takes kSumBlocks consecutive 64-row blocks, so that as many independent chains (presence byte ->
+// base -> partial results) are in flight per wave: with one block per wave the pass is bound by the three
+// dependent round trips, not by its bytes.
+constexpr int kSumBlocks = 4;
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void sum_partials_kernel(int rows, int nblk, const unsigned char *__restrict__ presence,
                                                               const int *__restrict__ base, const T *__restrict__ part,
                                                               T *__restrict__ y)
 {
-    const int r = (int)(blockIdx.x * kBlock + threadIdx.x);
-    const unsigned bits = r < rows ? presence[r] : 0u;
-    const int blk = __builtin_amdgcn_readfirstlane(r >> 6);
-    const unsigned long long before = (1ull << (threadIdx.x & 63)) - 1ull;
-    T p[8];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int blk0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave) * kSumBlocks);
+    const unsigned long long before = (1ull << lane) - 1ull;
+    unsigned bits[kSumBlocks];
 #pragma unroll
-    for (int g = 0; g < 8; g++) {
-        const bool has = (bits >> g) & 1u;
-        const unsigned long long mask = __ballot(has);
-        p[g] = 0;
-        if (has) p[g] = __builtin_nontemporal_load(part + base[(size_t)g * nblk + blk] + __popcll(mask & before));
+    for (int k = 0; k < kSumBlocks; k++) {
+        const int r = (blk0 + k) * kWave + lane;
+        bits[k] = r < rows ? presence[r] : 0u;
     }
-    T s = p[0];
+    T p[kSumBlocks][8];
 #pragma unroll
-    for (int g = 1; g < 8; g++) s += p[g];
-    if (r < rows) y[r] = s;
+    for (int k = 0; k < kSumBlocks; k++) {
+        const int blk = min(blk0 + k, nblk - 1);               // blocks past the end have no presence bits set
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            const bool has = (bits[k] >> g) & 1u;
+            const unsigned long long mask = __ballot(has);
+            p[k][g] = 0;
+            if (has) p[k][g] = __builtin_nontemporal_load(part + base[(size_t)g * nblk + blk] + __popcll(mask & before));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kSumBlocks; k++) {
+        T s = p[k][0];
+#pragma unroll
+        for (int g = 1; g < 8; g++) s += p[k][g];
+        const int r = (blk0 + k) * kWave + lane;
+        if (r < rows) y[r] = s;
+    }
 }
 
 template <typename T>
@@ -1641,7 +1659,7 @@ static int launch_mult_xcd(const spmv_hip_matrix *m, const T *x, T *y, hipStream
         hipLaunchKernelGGL((permute_x_groups_kernel<T>), dim3(cdiv(m->xcd_used_cpx, kBlock), 8), dim3(kBlock), 0, st,
                            m->xcd_used_cpx, m->xcd_cpx, m->d_hot_old, x, (T *)m->d_hot_x);
     if (launch_mult(m->xcd_sub, m->d_hot_x, m->d_xcd_y, st)) return 1;
-    hipLaunchKernelGGL((sum_partials_kernel<T>), dim3(cdiv(m->rows, kBlock)), dim3(kBlock), 0, st, m->rows,
+    hipLaunchKernelGGL((sum_partials_kernel<T>), dim3(cdiv(m->rows, kBlock * kSumBlocks)), dim3(kBlock), 0, st, m->rows,
                        (m->rows + kWave - 1) / kWave, m->d_xcd_presence, m->d_xcd_base, (const T *)m->d_xcd_y, y);
     SPMV_HIP_TRY(hipGetLastError(), return 1);
     return 0;
