@@ -52,6 +52,21 @@ __global__ __launch_bounds__(256) void direct(const double *val, const int *col,
     else if (acc == 12345.678) out[0] = acc;
 }
 
+// one wave per slice; the result leaves as an atomic without return value (performed in the L2, whose line then
+// stays dirty until it is evicted, instead of a store that the L2 writes through at once): MODE 0 exchange, 1 add
+template <int U, bool NT, int MODE>
+__global__ __launch_bounds__(256) void direct_atomic(const double *val, const int *col, int nslices, int W, double *y)
+{
+    unsigned b = xcd_block(blockIdx.x, gridDim.x);
+    int s = __builtin_amdgcn_readfirstlane((int)(b * 4 + threadIdx.x / 64));
+    if (s >= nslices) return;
+    int lane = threadIdx.x & 63;
+    double acc = slice_sum<U, NT>(val, col, s, W, lane);
+    double *p = y + (size_t)s * 64 + lane;
+    if (MODE == 0) (void)__hip_atomic_exchange(p, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else (void)__hip_atomic_fetch_add(p, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // one wave per slice; only every K-th slice stores its result (MODE 0), or every slice stores into a ring of
 // `wrap` doubles (MODE 1), or every K-th WORKGROUP (4 consecutive slices) stores (MODE 2)
 template <int U, bool NT, int MODE>
@@ -249,7 +264,7 @@ int main()
     CK(hipMemset(val, 0, n * 8)); CK(hipMemset(col, 0, n * 4));
     const double gb = n * 12 / 1e9;
     unsigned g = (nslices + 3) / 4;
-    const bool writer_only = getenv("PHASEBENCH_WRITER_ONLY") != nullptr || getenv("PHASEBENCH_YTYPES") != nullptr;
+    const bool writer_only = getenv("PHASEBENCH_WRITER_ONLY") != nullptr || getenv("PHASEBENCH_YTYPES") != nullptr || getenv("PHASEBENCH_ATOMIC") != nullptr;
 #define RUN(NAME, ...) { double t = time_ms([&] { __VA_ARGS__; }); printf("%-58s %.4f ms  %.1f GB/s\n", NAME, t, gb / t * 1e3); fflush(stdout); }
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
@@ -306,6 +321,13 @@ int main()
         printf("%-58s %.4f ms  %.1f GB/s\n", name, t, gb / t * 1e3); fflush(stdout);
         (void)sync;
     };
+    if (getenv("PHASEBENCH_ATOMIC")) {
+        RUN("direct U9 nt    nostore", hipLaunchKernelGGL((direct<9, true, false>), dim3(g), dim3(256), 0, 0, val, col, nslices, W, y, out));
+        RUN("direct U9 nt    store", hipLaunchKernelGGL((direct<9, true, true>), dim3(g), dim3(256), 0, 0, val, col, nslices, W, y, out));
+        RUN("direct U9 nt    atomic exchange instead of the store", hipLaunchKernelGGL((direct_atomic<9, true, 0>), dim3(g), dim3(256), 0, 0, val, col, nslices, W, y));
+        RUN("direct U9 nt    atomic add instead of the store", hipLaunchKernelGGL((direct_atomic<9, true, 1>), dim3(g), dim3(256), 0, 0, val, col, nslices, W, y));
+        return 0;
+    }
     if (getenv("PHASEBENCH_YTYPES")) {
         // the same store into y allocated in other ways
         struct { const char *name; unsigned flags; } kinds[] = {{"hipMalloc", 0xffffffffu}, {"fine-grained", hipDeviceMallocFinegrained},
