@@ -430,10 +430,19 @@ static int dist_exchange_and_multiply(spmv_hip_dist *d)
 {
     const size_t es = dtype_size(d->dtype);
     const int P = d->ngpus;
-    // 1. every block packs what the others need and pushes it to them on its communication stream
+    // One host thread issues everything, so the order of issue matters: first every block's interior product
+    // (it needs no communication and is nearly all of the work), so that every GPU is busy within a few launch
+    // latencies; then, while those run, the packing and the pushes on the communication streams; last the
+    // boundary rows.
+    // 1. x of this product is in place on the compute stream: mark it, then start the interior rows
+    for (int p = 0; p < P; p++) {
+        SPMV_HIP_TRY(hipSetDevice(d->device[p]), return 1);
+        SPMV_HIP_TRY(hipEventRecord(d->x_ready[p], d->compute[p]), return 1);
+        if (spmv_hip_rowblock_mult_interior(d->block[p], d->d_x[p], d->d_y[p], d->compute[p])) return 1;
+    }
+    // 2. every block packs what the others need and pushes it to them on its communication stream
     for (int q = 0; q < P; q++) {
         SPMV_HIP_TRY(hipSetDevice(d->device[q]), return 1);
-        SPMV_HIP_TRY(hipEventRecord(d->x_ready[q], d->compute[q]), return 1);
         SPMV_HIP_TRY(hipStreamWaitEvent(d->comm[q], d->x_ready[q], 0), return 1);
         if (spmv_hip_rowblock_pack(d->block[q], d->d_x[q], d->d_send[q], d->comm[q])) return 1;
         for (int p = 0; p < P; p++) {
@@ -445,11 +454,7 @@ static int dist_exchange_and_multiply(spmv_hip_dist *d)
         }
         SPMV_HIP_TRY(hipEventRecord(d->sent[q], d->comm[q]), return 1);
     }
-    // 2. interior products run meanwhile; 3. the boundary rows once every sender's pushes have landed
-    for (int p = 0; p < P; p++) {
-        SPMV_HIP_TRY(hipSetDevice(d->device[p]), return 1);
-        if (spmv_hip_rowblock_mult_interior(d->block[p], d->d_x[p], d->d_y[p], d->compute[p])) return 1;
-    }
+    // 3. the boundary rows once every sender's pushes have landed
     for (int p = 0; p < P; p++) {
         SPMV_HIP_TRY(hipSetDevice(d->device[p]), return 1);
         for (int q = 0; q < P; q++)
