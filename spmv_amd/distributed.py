@@ -279,16 +279,20 @@ class RowBlockSpmv:
             return y
         if x.data_ptr() != self.x_local.data_ptr():
             self.x_local.copy_(x)
-        if self.nsend:
-            self.block.pack(self.x_local, self.send_buf)
         if self.on_gpu:
+            # order of issue: the interior product first, so that the GPU is busy while the host posts the
+            # packing and the exchange on the side stream (which only waits for x, not for that product)
             main = torch.cuda.current_stream()
             self.comm_stream.wait_stream(main)
+            self.block.mult_interior(self.x_local, y)
             with torch.cuda.stream(self.comm_stream):
+                if self.nsend:
+                    self.block.pack(self.x_local, self.send_buf)
                 self._exchange_halo()
-            self.block.mult_interior(self.x_local, y)           # overlaps the exchange
             main.wait_stream(self.comm_stream)
         else:
+            if self.nsend:
+                self.block.pack(self.x_local, self.send_buf)
             self._exchange_halo()
             self.block.mult_interior(self.x_local, y)
         self.block.mult_boundary(self.x_ext, y)
