@@ -255,6 +255,23 @@ class RowBlockSpmv:
                 t.copy_(host_r[q])
 
     def _exchange_halo(self):
+        if not self.stage_host and self.world > 1:
+            # the buffers never move: build the group of sends and receives once, post it every product
+            ops = getattr(self, "_halo_ops", None)
+            if ops is None:
+                ops, off = [], 0
+                for q in self.peers_send:
+                    n = self.send_counts[q]
+                    ops.append(dist.P2POp(dist.isend, self.send_buf[off:off + n], q, group=self.group))
+                    off += n
+                for q in self.peers_recv:
+                    a, b = self.recv_ranges[q]
+                    ops.append(dist.P2POp(dist.irecv, self.halo_buf[a:b], q, group=self.group))
+                self._halo_ops = ops
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            return
         sends, off = {}, 0
         for q in self.peers_send:
             n = self.send_counts[q]
