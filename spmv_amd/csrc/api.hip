@@ -636,6 +636,11 @@ int spmv_hip_set_option(spmv_hip_matrix *m, const char *name, int64_t value)
     if (!strcmp(name, "variant")) { m->variant = (int)value; return 0; }
     if (!strcmp(name, "hot_variant")) {                     // the tile kernel of the stacked matrix behind hot_columns 2
         if (!m->xcd_sub) { set_error("hot_variant needs hot_columns 2"); return 1; }
+        int cand[32];
+        const int n = variant_candidates(m->xcd_sub, cand, 32);
+        bool known = false;
+        for (int i = 0; i < n; i++) known = known || cand[i] == (int)value;
+        if (!known) { set_error("hot_variant %lld is not a tile kernel of this handle (0, 1, 3, 4)", (long long)value); return 1; }
         m->xcd_sub->variant = (int)value;
         return 0;
     }

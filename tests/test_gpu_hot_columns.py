@@ -141,6 +141,8 @@ def test_hot_labels_in_lds_on_a_graph_matrix(orc, dt):
     m.set_option("hot_variant", 1)
     tiles = m.mult(x)
     assert orc.rel_l2(tiles, want) <= (1e-13 if dt == S.F64 else 2e-6)
+    with pytest.raises(S.SpmvHipError, match="not a tile kernel"):
+        m.set_option("hot_variant", 7)
     for hv in (3, 4):
         m.set_option("hot_variant", hv)
         for _ in range(2):                                  # the second product finds the LDS of the first one's workgroups gone
