@@ -20,7 +20,7 @@ for mode in csr_base csr_vec csr_merge csr_bal ell sellp_vec sell:1024 sell_dfc:
         mv "$out/tmp/0.csv" "$out/$tag.csv"
         if [ $first = 1 ]; then head -1 "$out/$tag.csv" > "$out/all.csv"; first=0; fi
         tail -n +2 "$out/$tag.csv" >> "$out/all.csv"
-        echo "$tag: $(grep -c ' OK' "$out/$tag.log") OK, $(grep -c ' ERR' "$out/$tag.log") ERR"
+        echo "$tag: $(grep -c ' OK' "$out/$tag.log") OK, $(grep -c ' ERR$' "$out/$tag.log") ERR"
     done
 done
 rm -rf "$out/tmp" "$root/matrices/standins_160"
