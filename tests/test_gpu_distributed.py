@@ -2,8 +2,8 @@
 
 The GPU box has a single MI355X, so both ranks use cuda:0 and talk over gloo
 (halo staged through the host); the local products, the interior/boundary split,
-the row-mapped boundary kernel and the stream ordering are the real ones.  The
-8-GPU RCCL run itself is done by the round-end driver.  Tolerance: rel-L2 <=
+the row-mapped boundary kernel and the stream ordering are the real ones.  A
+multi-rank RCCL run needs one GPU per rank.  Tolerance: rel-L2 <=
 1e-13 against the oracle's single-process product (analyze() may pick a
 reassociating SELL kernel).
 """

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Profile the headline benchmark with rocprofv3: a kernel-trace pass of `python3 bench.py` exactly as the
-# round-end driver runs it (durations), then one PMC pass each for FETCH_SIZE and WRITE_SIZE of the
+# Profile the headline benchmark with rocprofv3: a kernel-trace pass of a plain `python3 bench.py`, all
+# defaults (durations), then one PMC pass each for FETCH_SIZE and WRITE_SIZE of the
 # kernel variant that run picked and of the every-index-read variant it reported, recorded in
 # profiles/hbm_traffic.json against the hash of the kernel sources.
 #   tools/profile_bench.sh r02        -> profiles/r02_bench_n1.json, r02_bench_n1_kernel_stats.csv, hbm_traffic.json
@@ -28,7 +28,7 @@ for v in $variant $general; do
     python3 "$root/tools/record_traffic.py" --key "sell/stencil27/252/f64/gpus1/variant$v" --fetch "$out/v${v}_FETCH_SIZE" --write "$out/v${v}_WRITE_SIZE" --source "tools/profile_bench.sh $tag (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --variant $v)" > "$out/v${v}_traffic.json"
 done
 rm -rf "$out/trace" "$out"/v*_FETCH_SIZE "$out"/v*_WRITE_SIZE
-# the line as the round-end driver will see it, now with the traffic record in place
+# the line a plain `python3 bench.py` prints, now with the traffic record in place
 timeout -k 10 400 python3 "$root/bench.py" > "$out/bench_final.json" 2> "$out/bench_final.err"
 tail -1 "$out/bench_final.json" > "$root/profiles/${tag}_bench_n1.json"
 # profiles/ does not travel back from a GPU box, gpurun_out/ does
