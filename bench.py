@@ -21,7 +21,16 @@ in profiles/hbm_traffic.json for exactly this kernel source (null otherwise),
 `frac_moved` the fraction of peak those bytes amount to; `roofline.general` is the
 same measurement for the fastest kernel variant that reads every column index.
 `cpu_baseline` times the compiled reference (oracle/_ref, kind "reference") or the
-oracle port on the host cores for a bounded sample of the same workload.
+oracle port on the host cores for a bounded sample of the same workload; it runs, in
+a child process, before this process makes its first GPU call.
+`other_configs` (N = 1, the default command only) carries the other single-GPU
+configurations of the benchmark list, each measured like the headline one: the 2-D
+5-point Laplacian 1000^2 on lane-per-row CSR (the format of csr.c) and on the format
+the trial picks, and the R-MAT scale 26 matrix on balanced CSR as it is and with its
+columns dealt over the XCDs (option hot_columns 2, with the time of its three kernels).
+For N > 1 the line also carries `rccl` (what the communicator reports) and
+`c_abi_one_process`: the same slabs driven by ONE process through spmv_hip_dist_*
+(peer-to-peer pushes between the GPUs), run in a child after the ranks have finished.
 """
 from __future__ import annotations
 
@@ -60,6 +69,16 @@ def parse_args(argv=None):
     ap.add_argument("--sigma", type=int, default=1024)
     ap.add_argument("--p0", type=int, default=0, help="format parameter (lanes per row / tile size / slice height)")
     ap.add_argument("--variant", type=int, default=-1, help="N = 1: this kernel variant instead of the one the trial picks")
+    ap.add_argument("--hot-columns", type=int, default=0, choices=[0, 1, 2],
+                    help="N = 1, CSR-based formats: option hot_columns (1 columns relabeled by reference count, 2 dealt over the XCDs)")
+    ap.add_argument("--hot-variant", type=int, default=-1, help="with --hot-columns 2: this tile kernel of the column-split copy")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="N = 1: skip the other single-GPU configurations (Laplacian 1000^2, R-MAT 26)")
+    ap.add_argument("--rmat-scale", type=int, default=26, help="R-MAT scale of the other_configs entry")
+    ap.add_argument("--no-one-process", action="store_true",
+                    help="N > 1: skip the run of the same slabs through spmv_hip_dist_* from one process")
+    ap.add_argument("--one-process-only", action="store_true",
+                    help="run only the one-process spmv_hip_dist_* leg over --gpus devices and print its JSON")
     ap.add_argument("--exchange", default="halo", choices=["halo", "allgather"])
     ap.add_argument("--no-comm-breakdown", action="store_true",
                     help="N > 1: skip timing the exchange alone and the local products alone after the timed region")
@@ -285,7 +304,146 @@ def launch_ranks(args, argv, script=None):
     return 0
 
 
+# ------------------------------------------------- one process over all GPUs --
+
+def one_process_child(args):
+    """The slabs of the N > 1 run behind ONE process and the C ABI: a spmv_hip_rowblock per GPU built from
+    its CSR shard in HBM, spmv_hip_dist_create_from_blocks, spmv_hip_dist_analyze, then the driver's
+    timed loop (spmv_hip_dist_bench: exchange by peer-to-peer pushes + products, host clock per product).
+    Before it, one product of x_i = i: on every row away from the grid's faces the stencil (centre 26,
+    26 neighbours -1, offsets symmetric) must give exactly 0.0 in any summation order -- every partial sum
+    is an integer below 2^53 -- so a halo entry that arrives late, or in the wrong slot, shows.
+    Prints one JSON object."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    import spmv_amd as S
+    from spmv_amd import _lib as L
+    from spmv_amd import generators as G
+
+    P = args.gpus
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("SPMV_BENCH_BACKEND", "nccl")
+    if ndev < 1 or (backend == "nccl" and ndev < P):
+        print(json.dumps({"error": f"{P} blocks need {P} GPUs, this node has {ndev}"}))
+        return 0
+    devices = [p % ndev for p in range(P)]
+    dtype = S.F64 if args.dtype == "f64" else S.F32
+    tdtype = torch.float64 if dtype == S.F64 else torch.float32
+    fmt = FORMATS[args.format]
+    p0 = args.p0 or (64 if fmt == S.SELL else 0)
+    p1 = args.sigma if fmt == S.SELL else 0
+    n = args.n or 252
+    plane = n * n
+    if args.total_planes:
+        nz_all = args.total_planes
+        cuts = [p * nz_all // P for p in range(P + 1)]
+    else:
+        nzp = args.planes or n
+        nz_all = nzp * P
+        cuts = [p * nzp for p in range(P + 1)]
+    lib = S.lib()
+    t_build = time.perf_counter()
+    blocks, nnz_total = [], 0
+    for p in range(P):
+        dev = torch.device("cuda", devices[p])
+        torch.cuda.set_device(dev)
+        L.check(lib.spmv_hip_init(devices[p]))
+        r0, r1 = cuts[p] * plane, cuts[p + 1] * plane
+        rows, cols, rp, cj, va = G.stencil27(n, n, nz_all, device=dev, row_begin=r0, row_end=r1)
+        va = va.to(tdtype)
+        nnz = int(rp[-1])
+        nnz_total += nnz
+        blocks.append(L.check_handle(lib.spmv_hip_rowblock_create(fmt, rows, r0, cols, nnz, rp.data_ptr(), cj.data_ptr(),
+                                                                 va.data_ptr(), dtype, p0, p1, 0)))
+        torch.cuda.synchronize()
+        del rp, cj, va
+        torch.cuda.empty_cache()
+    arr = (C.c_void_p * P)(*blocks)
+    d = L.check_handle(lib.spmv_hip_dist_create_from_blocks(P, arr))
+    L.check(lib.spmv_hip_dist_analyze(d, 3))
+    build_s = time.perf_counter() - t_build
+    access = np.zeros(P * P, np.int32)
+    L.check(lib.spmv_hip_dist_get_peer_access(d, access.ctypes.data_as(C.c_void_p)))
+    pairs = [access[q * P + p] for q in range(P) for p in range(P) if p != q]
+    info = (L.RowBlockInfo * P)()
+    L.check(lib.spmv_hip_dist_get_info(d, None, None, info))
+    total_rows = plane * nz_all
+    out = {"blocks": P, "devices": devices, "format": args.format, "dtype": args.dtype, "rows": total_rows, "nnz": nnz_total,
+           "halo_per_block": [b.halo for b in info], "interior_variant": [b.interior_variant for b in info],
+           "peer_access": {"direct": int(sum(v == 1 for v in pairs)), "through_host": int(sum(v == 0 for v in pairs)),
+                           "same_device": int(sum(v == 2 for v in pairs))},
+           "helper_threads": os.environ.get("SPMV_DIST_THREADS", "1") != "0", "build_seconds": round(build_s, 2)}
+    if dtype == S.F64:
+        x = np.arange(total_rows, dtype=np.float64)
+        y = np.full(total_rows, np.nan)
+        L.check(lib.spmv_hip_dist_mult(d, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p)))
+        g = y.reshape(nz_all, n, n)[1:-1, 1:-1, 1:-1]
+        bad = int(np.count_nonzero(g))
+        out["halo_check"] = {"product": "x_i = i: exactly 0.0 on every row away from the grid's faces", "rows_checked": int(g.size),
+                             "rows_wrong": bad, "ok": bad == 0 and bool(np.isfinite(y).all())}
+        del x, y, g
+    rng = np.random.default_rng(1234)
+    x = rng.random(total_rows)
+    x /= np.linalg.norm(x)
+    it, sec = C.c_int(0), C.c_double(0.0)
+    # the helper threads' first launches pay the runtime's per-thread set-up (the first ~50 products of a new handle
+    # run several times slower): 100 untimed products before the warm-up the command line asks for
+    L.check(lib.spmv_hip_dist_bench(d, 100, 0.0, x.ctypes.data_as(C.c_void_p), C.byref(it), C.byref(sec)))
+    if args.warmup > 0:
+        L.check(lib.spmv_hip_dist_bench(d, args.warmup, 0.0, x.ctypes.data_as(C.c_void_p), C.byref(it), C.byref(sec)))
+    L.check(lib.spmv_hip_dist_bench(d, args.steps, 0.0, x.ctypes.data_as(C.c_void_p), C.byref(it), C.byref(sec)))
+    ms = sec.value / it.value * 1e3
+    vbytes = 8 if dtype == S.F64 else 4
+    out.update({"steps": it.value, "ms_per_step": round(ms, 5), "value": round(2.0 * nnz_total / ms / 1e6, 2), "unit": "GFLOP/s",
+                "timing": "host clock around each product, from the first launch to the last block's completion (spmv_hip_dist_bench)",
+                "algorithmic_gbs": round(algorithmic_bytes(total_rows, total_rows, nnz_total, vbytes) / ms / 1e6, 1)})
+    lib.spmv_hip_dist_free(d)
+    print(json.dumps(out), flush=True)
+    return 0
+
+
+def one_process_leg(argv, gpus):
+    """Runs one_process_child in a child process of its own (it drives every GPU of the node) and returns its
+    record; a failure there becomes {"error": ...} and never costs the rank's own result line."""
+    keep = [a for a in argv if a not in ("--no-comm-breakdown",)]
+    cmd = [sys.executable, os.path.abspath(__file__)] + keep + ["--one-process-only"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                              "GROUP_RANK", "LOCAL_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE")}
+    try:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+    except subprocess.TimeoutExpired:
+        return {"error": "the one-process leg did not finish within 420 s"}
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    if out.returncode != 0 or not lines:
+        return {"error": f"exit status {out.returncode}: {(out.stderr or out.stdout)[-600:]}"}
+    return json.loads(lines[-1])
+
+
 # ------------------------------------------------------------------------- main --
+
+FORMATS = {}            # name -> library constant, filled on first use (the import must not precede the rank launcher)
+
+
+def _formats():
+    import spmv_amd as S
+    if not FORMATS:
+        FORMATS.update({"sell": S.SELL, "sellp": S.SELLP, "ell": S.ELL, "csr_scalar": S.CSR_SCALAR, "csr_vector": S.CSR_VECTOR,
+                        "csr_merge": S.CSR_MERGE, "csr_bal": S.CSR_BAL, "sell_dfc": S.SELL_DFC})
+    return FORMATS
+
+
+def traffic_key(fmt_name, matrix, n, dtype_name, world, info):
+    """Name of a configuration in profiles/hbm_traffic.json."""
+    v = f"variant{info.variant}"
+    if fmt_name == "csr_vector":
+        v += f"lanes{info.lanes_per_row}"
+    if info.hot_columns == 1:
+        v += "+hot1"
+    elif info.hot_columns == 2:
+        v += f"+hot2tiles{info.hot_variant}"
+    return f"{fmt_name}/{matrix}/{n}/{dtype_name}/gpus{world}/{v}"
+
 
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
@@ -293,6 +451,9 @@ def main(argv=None):
     if args.cpu_baseline_only:
         cpu_baseline_child(args.cpu_n)
         return 0
+    if args.one_process_only:
+        _formats()
+        return one_process_child(args)
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         return launch_ranks(args, argv)
@@ -300,6 +461,12 @@ def main(argv=None):
     if world != args.gpus:
         print(f"bench.py: WORLD_SIZE is {world} but --gpus is {args.gpus}; launch one rank per GPU", file=sys.stderr)
         return 2
+
+    # the host-CPU baseline first, in a child of its own: this process has not touched a GPU yet, and the
+    # child's threads have the host to themselves
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.cpu_n)
 
     import torch
     import torch.distributed as dist
@@ -326,89 +493,8 @@ def main(argv=None):
         else:
             dist.init_process_group(backend)
 
-    dtype = S.F64 if args.dtype == "f64" else S.F32
-    tdtype = torch.float64 if dtype == S.F64 else torch.float32
-    vbytes = 8 if dtype == S.F64 else 4
-    fmt = {"sell": S.SELL, "sellp": S.SELLP, "ell": S.ELL, "csr_scalar": S.CSR_SCALAR, "csr_vector": S.CSR_VECTOR,
-           "csr_merge": S.CSR_MERGE, "csr_bal": S.CSR_BAL}[args.format]
-    p0 = args.p0 or (64 if fmt == S.SELL else 0)
-    p1 = args.sigma if fmt == S.SELL else 0
+    formats = _formats()
     stream = torch.cuda.current_stream().cuda_stream
-
-    # ---- workload -----------------------------------------------------------
-    if world > 1 and args.matrix != "stencil27":
-        print("bench.py: the multi-GPU bench is defined on the stencil27 workload", file=sys.stderr)
-        return 2
-    if args.matrix == "stencil27":
-        n = args.n or 252
-        if world == 1:
-            rows, cols, rp, cj, va = G.stencil27(n, device=dev)
-            workload = f"stencil27 {n}^3"
-        else:
-            plane = n * n
-            if args.total_planes:           # 530^3 over 8 GPUs: --size 530 --total-planes 530 (slabs of 66 or 67 planes)
-                nz_all = args.total_planes
-                p0_, p1_ = rank * nz_all // world, (rank + 1) * nz_all // world
-                workload = f"stencil27 {n}x{n}x{nz_all}, z-slabs of {nz_all // world}..{-(-nz_all // world)} planes per GPU"
-            else:
-                nzp = args.planes or n
-                nz_all = nzp * world
-                p0_, p1_ = rank * nzp, (rank + 1) * nzp
-                workload = f"stencil27 {n}x{n}x{nz_all}, z-slab of {nzp} planes per GPU"
-            r0, r1 = p0_ * plane, p1_ * plane
-            rows, cols, rp, cj, va = G.stencil27(n, n, nz_all, device=dev, row_begin=r0, row_end=r1)
-    elif args.matrix == "laplacian2d":
-        n = args.n or 1000
-        rows, cols, rp, cj, va = G.laplacian2d(n, device=dev)
-        workload = f"laplacian2d {n}^2"
-    else:
-        n = args.n or 22
-        rows, cols, rp, cj, va = G.rmat(n, 16, device=dev)
-        workload = f"rmat scale {n} edge factor 16"
-    nnz = int(rp[-1])
-    va = va.to(tdtype)
-
-    m = op = None
-    if world == 1:
-        m = Matrix.from_device_csr(fmt, rows, cols, nnz, rp.data_ptr(), cj.data_ptr(), va.data_ptr(), dtype, p0, p1,
-                                   stream, keepalive=(rp, cj, va))
-        if args.variant >= 0:
-            m.set_option("variant", args.variant)
-        else:
-            m.analyze(3)       # kernel variant by trial, as create_sell does (reference sell.c:30)
-        if fmt in (S.SELL, S.SELLP, S.ELL):
-            m._keepalive = None
-            del rp, cj, va
-            torch.cuda.empty_cache()
-        g = torch.Generator(device=dev).manual_seed(1234)
-        x = torch.rand(cols, dtype=tdtype, device=dev, generator=g)
-        x /= torch.linalg.vector_norm(x)
-        y = torch.empty(rows, dtype=tdtype, device=dev)
-
-        def step():
-            m.mult_dev(x.data_ptr(), y.data_ptr(), stream)
-        info = m.info
-        stored, variant = info.stored, info.variant
-        global_rows, global_nnz = rows, nnz
-    else:
-        from spmv_amd.distributed import RowBlockSpmv
-        op = RowBlockSpmv(fmt, rows, cols, rp, cj, va, dtype, p0, p1, row_begin=r0, exchange=args.exchange,
-                          device=dev)
-        del rp, cj, va
-        torch.cuda.empty_cache()
-        g = torch.Generator(device=dev).manual_seed(1234 + rank)
-        x = torch.rand(rows, dtype=tdtype, device=dev, generator=g)
-        y = torch.empty(rows, dtype=tdtype, device=dev)
-        if op.A_glob is None:                 # halo exchange: x lives in the operator's extended vector,
-            op.x_local.copy_(x)               # so a step starts from it without a 128 MB copy
-            x = op.x_local
-
-        def step():
-            op.mult(x, y)
-        stored, variant = op.stored, op.variant
-        t = torch.tensor([nnz, rows], dtype=torch.int64, device=dev)
-        dist.all_reduce(t)
-        global_nnz, global_rows = int(t[0].item()), int(t[1].item())
 
     def timed_region(fn, steps, warmup):
         """`warmup` untimed steps, then exactly `steps` bracketed by barrier + synchronize on both sides.
@@ -437,14 +523,216 @@ def main(argv=None):
             elapsed = float(tt.item())
         return elapsed, sorted(s.elapsed_time(e) for s, e in zip(starts, ends))
 
-    # ---- timed region -------------------------------------------------------
+    def roofline_record(b_alg, mean_ms, ms_sorted, key, v):
+        achieved = b_alg / (mean_ms * 1e-3) / 1e9
+        traffic, note = recorded_traffic(key)
+        rec = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+               "frac_moved": round(traffic / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+               "traffic_source": note if traffic else None,
+               "algorithmic_bytes_per_launch": b_alg, "kernel_variant": v, "kernel_ms_mean": round(mean_ms, 5),
+               "kernel_ms_min": round(ms_sorted[0], 5), "kernel_ms_median": round(ms_sorted[len(ms_sorted) // 2], 5)}
+        if traffic is None:
+            print(f"bench.py: roofline.traffic is null: {note}", file=sys.stderr)
+        return rec
+
+    def generate(matrix, n):
+        if matrix == "stencil27":
+            return G.stencil27(n, device=dev), f"stencil27 {n}^3"
+        if matrix == "laplacian2d":
+            return G.laplacian2d(n, device=dev), f"laplacian2d {n}^2"
+        return G.rmat(n, 16, device=dev), f"rmat scale {n} edge factor 16"
+
+    index_skipping = {S.SELL: range(16, 24), S.SELLP: range(16, 24), S.ELL: range(16, 24), S.CSR_SCALAR: range(16, 23),
+                      S.CSR_VECTOR: (7, 8), S.CSR_MERGE: (2,), S.CSR_BAL: (2,), S.SELL_DFC: range(9, 13)}
+    every_index = {S.SELL: (0, 1, 2, 3, 4, 9, 10, 11, 12), S.SELLP: (0, 1, 2, 3, 4, 9, 10, 11, 12),
+                   S.ELL: (0, 1, 2, 3, 4, 9, 10, 11, 12), S.CSR_SCALAR: (0, 2, 3, 4, 8, 10, 11, 12),
+                   S.CSR_VECTOR: (5, 6), S.CSR_MERGE: (0, 1), S.CSR_BAL: (0, 1), S.SELL_DFC: tuple(range(0, 9))}
+
+    def single_gpu_config(matrix, n, fmt_name, dtype_name, sigma=1024, p0_arg=0, variant=-1, hot=0, hot_variant=-1, steps=20,
+                          warmup=3, want_general=False, csr=None):
+        """One configuration on this GPU, measured like the headline one.  fmt_name "auto": the format the
+        library's trial picks (spmv_hip_create_auto_from_device_csr).  `csr`: a generated matrix to reuse."""
+        dtype = S.F64 if dtype_name == "f64" else S.F32
+        tdtype = torch.float64 if dtype == S.F64 else torch.float32
+        vbytes = 8 if dtype == S.F64 else 4
+        (rows, cols, rp, cj, va), workload = csr if csr is not None else generate(matrix, n)
+        nnz = int(rp[-1])
+        va = va.to(tdtype)
+        if fmt_name == "auto":
+            m = Matrix.auto_from_device_csr(rows, cols, nnz, rp.data_ptr(), cj.data_ptr(), va.data_ptr(), dtype, 3, stream,
+                                            keepalive=(rp, cj, va))
+            fmt = m.info.format
+            fmt_name = S.FORMAT_NAMES[fmt]
+        else:
+            fmt = formats[fmt_name]
+            p0 = p0_arg or (64 if fmt in (S.SELL, S.SELL_DFC) else 0)
+            p1 = sigma if fmt in (S.SELL, S.SELL_DFC) else 0
+            m = Matrix.from_device_csr(fmt, rows, cols, nnz, rp.data_ptr(), cj.data_ptr(), va.data_ptr(), dtype, p0, p1,
+                                       stream, keepalive=(rp, cj, va))
+            if hot:
+                m.set_option("hot_columns", hot)
+            if variant >= 0:
+                m.set_option("variant", variant)
+                if hot == 2 and hot_variant >= 0:
+                    m.set_option("hot_variant", hot_variant)
+            else:
+                m.analyze(3)       # kernel variant by trial, as create_sell does (reference sell.c:30)
+        if fmt in (S.SELL, S.SELLP, S.ELL, S.SELL_DFC):      # the sliced layouts are copies: the CSR arrays may go
+            m._keepalive = None
+        del rp, cj, va
+        torch.cuda.empty_cache()
+        g = torch.Generator(device=dev).manual_seed(1234)
+        x = torch.rand(cols, dtype=tdtype, device=dev, generator=g)
+        x /= torch.linalg.vector_norm(x)
+        y = torch.empty(rows, dtype=tdtype, device=dev)
+
+        def step():
+            m.mult_dev(x.data_ptr(), y.data_ptr(), stream)
+        elapsed, kernel_ms = timed_region(step, steps, warmup)
+        info = m.info
+        b_alg = algorithmic_bytes(rows, cols, nnz, vbytes)
+        res = {"workload": workload, "format": fmt_name, "fmt": fmt, "dtype": dtype_name, "rows": rows, "cols": cols, "nnz": nnz,
+               "stored": int(info.stored), "variant": info.variant, "lanes_per_row": info.lanes_per_row,
+               "hot_columns": info.hot_columns, "hot_variant": info.hot_variant, "elapsed": elapsed, "kernel_ms": kernel_ms,
+               "b_alg": b_alg, "key": traffic_key(fmt_name, matrix, n, dtype_name, 1, info), "general": None}
+        # outside the timed region: the fastest variant of the same handle that reads every column index
+        # (what a matrix without grid structure gets), measured the same way
+        if want_general and not info.hot_columns and info.variant in index_skipping[fmt]:
+            trial = {}
+            for v in every_index[fmt]:
+                m.set_option("variant", v)
+                _, ms = timed_region(step, 5, 2)
+                trial[v] = ms[len(ms) // 2]
+            gv = min(trial, key=trial.get)
+            m.set_option("variant", gv)
+            _, gms = timed_region(step, steps, warmup)
+            gkey = traffic_key(fmt_name, matrix, n, dtype_name, 1, m.info)
+            res["general"] = roofline_record(b_alg, sum(gms) / len(gms), gms, gkey, gv)
+            m.set_option("variant", info.variant)
+        m.free()
+        del x, y
+        torch.cuda.empty_cache()
+        return res
+
+    def other_entry(name, res):
+        """One line of `other_configs` from a single_gpu_config result."""
+        ms = res["kernel_ms"]
+        mean = sum(ms) / len(ms)
+        rec = roofline_record(res["b_alg"], mean, ms, res["key"], res["variant"])
+        entry = {"config": name, "workload": res["workload"], "format": res["format"], "dtype": res["dtype"],
+                 "rows": res["rows"], "nnz": res["nnz"], "kernel_variant": res["variant"], "hot_columns": res["hot_columns"],
+                 "ms": round(mean, 5), "ms_median": rec["kernel_ms_median"], "gflops": round(2.0 * res["nnz"] / mean / 1e6, 1),
+                 "frac": rec["frac"], "algorithmic_bytes_per_launch": res["b_alg"], "traffic": rec["traffic"],
+                 "frac_moved": rec["frac_moved"], "traffic_key": res["key"]}
+        if res["format"] == "csr_vector":
+            entry["lanes_per_row"] = res["lanes_per_row"]
+        if res["hot_columns"] == 2:
+            entry["hot_variant"] = res["hot_variant"]
+            table = {}
+            try:
+                table = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+            except OSError:
+                pass
+            rec_k = table.get(res["key"], {})
+            if rec_k.get("kernel_sources_sha256") == kernel_source_hash() and "kernels" in rec_k:
+                entry["kernels"] = rec_k["kernels"]      # per kernel of the product: ms and HBM bytes (rocprofv3 passes)
+        return entry
+
+    if world > 1 and args.matrix != "stencil27":
+        print("bench.py: the multi-GPU bench is defined on the stencil27 workload", file=sys.stderr)
+        return 2
+    dtype = S.F64 if args.dtype == "f64" else S.F32
+    tdtype = torch.float64 if dtype == S.F64 else torch.float32
+    vbytes = 8 if dtype == S.F64 else 4
+    fmt = formats[args.format]
+    n = args.n or {"stencil27": 252, "laplacian2d": 1000, "rmat": 22}[args.matrix]
+
+    if world == 1:
+        # ---- the headline configuration (or the one the flags name) -----------------
+        res = single_gpu_config(args.matrix, n, args.format, args.dtype, args.sigma, args.p0, args.variant, args.hot_columns,
+                                args.hot_variant, args.steps, args.warmup, want_general=not args.no_general)
+        kernel_ms = res["kernel_ms"]
+        mean_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+        ms_per_step = res["elapsed"] * 1e3 / args.steps
+        out = {
+            "metric": METRIC,
+            "value": round(2.0 * res["nnz"] / (ms_per_step * 1e-3) / 1e9, 2), "unit": "GFLOP/s", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": res["workload"], "format": args.format,
+                       "params": {"C": 64, "sigma": args.sigma} if fmt == S.SELL else {"p0": args.p0},
+                       "rows": res["rows"], "nnz": res["nnz"], "stored_per_gpu": res["stored"], "kernel_variant": res["variant"],
+                       "hot_columns": res["hot_columns"], "exchange": None},
+            "roofline": roofline_record(res["b_alg"], mean_kernel_ms, kernel_ms, res["key"], res["variant"]),
+        }
+        if res["general"] is not None:
+            out["roofline"]["general"] = res["general"]
+        # ---- the other single-GPU configurations of the benchmark list ---------------
+        default_run = (args.matrix, n, args.format, args.dtype, args.variant, args.hot_columns) == ("stencil27", 252, "sell", "f64", -1, 0)
+        if default_run and not args.no_other_configs:
+            others = []
+            lap = generate("laplacian2d", 1000)
+            others.append(other_entry("C1: plain CSR, the format of csr.c (lane per row)",
+                                      single_gpu_config("laplacian2d", 1000, "csr_scalar", "f64", csr=lap)))
+            others.append(other_entry("C1: the format the library's trial picks",
+                                      single_gpu_config("laplacian2d", 1000, "auto", "f64", csr=lap)))
+            del lap
+            torch.cuda.empty_cache()
+            rm = generate("rmat", args.rmat_scale)
+            others.append(other_entry("C3: balanced CSR as it is", single_gpu_config("rmat", args.rmat_scale, "csr_bal", "f64", csr=rm)))
+            others.append(other_entry("C3: balanced CSR, columns dealt over the XCDs (hot_columns 2)",
+                                      single_gpu_config("rmat", args.rmat_scale, "csr_bal", "f64", hot=2, csr=rm)))
+            del rm
+            torch.cuda.empty_cache()
+            out["other_configs"] = others
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
+        return 0
+
+    # ---- N > 1: one z-slab of the stencil per rank ----------------------------------
+    p0 = args.p0 or (64 if fmt == S.SELL else 0)
+    p1 = args.sigma if fmt == S.SELL else 0
+    plane = n * n
+    if args.total_planes:           # 530^3 over 8 GPUs: --size 530 --total-planes 530 (slabs of 66 or 67 planes)
+        nz_all = args.total_planes
+        p0_, p1_ = rank * nz_all // world, (rank + 1) * nz_all // world
+        workload = f"stencil27 {n}x{n}x{nz_all}, z-slabs of {nz_all // world}..{-(-nz_all // world)} planes per GPU"
+    else:
+        nzp = args.planes or n
+        nz_all = nzp * world
+        p0_, p1_ = rank * nzp, (rank + 1) * nzp
+        workload = f"stencil27 {n}x{n}x{nz_all}, z-slab of {nzp} planes per GPU"
+    r0, r1 = p0_ * plane, p1_ * plane
+    rows, cols, rp, cj, va = G.stencil27(n, n, nz_all, device=dev, row_begin=r0, row_end=r1)
+    nnz = int(rp[-1])
+    va = va.to(tdtype)
+    from spmv_amd.distributed import RowBlockSpmv
+    op = RowBlockSpmv(fmt, rows, cols, rp, cj, va, dtype, p0, p1, row_begin=r0, exchange=args.exchange, device=dev)
+    del rp, cj, va
+    torch.cuda.empty_cache()
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.rand(rows, dtype=tdtype, device=dev, generator=g)
+    y = torch.empty(rows, dtype=tdtype, device=dev)
+    if op.A_glob is None:                 # halo exchange: x lives in the operator's extended vector,
+        op.x_local.copy_(x)               # so a step starts from it without a 128 MB copy
+        x = op.x_local
+
+    def step():
+        op.mult(x, y)
+    stored, variant = op.stored, op.variant
+    t = torch.tensor([nnz, rows], dtype=torch.int64, device=dev)
+    dist.all_reduce(t)
+    global_nnz, global_rows = int(t[0].item()), int(t[1].item())
+
     elapsed, kernel_ms = timed_region(step, args.steps, args.warmup)
     mean_kernel_ms = sum(kernel_ms) / len(kernel_ms)
 
     # outside the timed region: the exchange alone and the local products alone, to say how much of
     # the communication the overlap hides (max over ranks of per-step means)
     comm = None
-    if world > 1 and not args.no_comm_breakdown:
+    if not args.no_comm_breakdown:
         def timed_ms(fn, reps=10):
             fn()
             torch.cuda.synchronize()
@@ -464,45 +752,16 @@ def main(argv=None):
                 "halo_entries_rank0": int(op.nhalo), "backend": backend,
                 "collectives": "batch_isend_irecv (one group of peer-to-peer sends/receives per product)"
                                if args.exchange == "halo" else "all_gather_into_tensor of x"}
-
-    # outside the timed region, N = 1: the fastest variant of the same handle that reads every column
-    # index (what a matrix without grid structure gets), measured the same way
-    b_alg = algorithmic_bytes(rows, cols if world == 1 else rows, nnz, vbytes)   # one launch, one GPU
-    general = None
-    index_skipping = {S.SELL: range(16, 24), S.SELLP: range(16, 24), S.ELL: range(16, 24), S.CSR_SCALAR: range(16, 23),
-                      S.CSR_VECTOR: (7, 8), S.CSR_MERGE: (2,), S.CSR_BAL: (2,)}[fmt]
-    if world == 1 and not args.no_general and variant in index_skipping:
-        every_index = {S.SELL: (0, 1, 2, 3, 4, 9, 10, 11, 12), S.SELLP: (0, 1, 2, 3, 4, 9, 10, 11, 12),
-                       S.ELL: (0, 1, 2, 3, 4, 9, 10, 11, 12), S.CSR_SCALAR: (0, 2, 3, 4, 8, 10, 11, 12),
-                       S.CSR_VECTOR: (5, 6), S.CSR_MERGE: (0, 1), S.CSR_BAL: (0, 1)}[fmt]
-        trial = {}
-        for v in every_index:
-            m.set_option("variant", v)
-            _, ms = timed_region(step, 5, 2)
-            trial[v] = ms[len(ms) // 2]
-        gv = min(trial, key=trial.get)
-        m.set_option("variant", gv)
-        _, gms = timed_region(step, args.steps, args.warmup)
-        g_mean = sum(gms) / len(gms)
-        m.set_option("variant", variant)
-
-    def roofline_record(mean_ms, ms_sorted, v):
-        achieved = b_alg / (mean_ms * 1e-3) / 1e9
-        key = f"{args.format}/{args.matrix}/{n}/{args.dtype}/gpus{world}/variant{v}"
-        traffic, note = recorded_traffic(key)
-        rec = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-               "frac_moved": round(traffic / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-               "traffic_source": note if traffic else None,
-               "algorithmic_bytes_per_launch": b_alg, "kernel_variant": v, "kernel_ms_mean": round(mean_ms, 5),
-               "kernel_ms_min": round(ms_sorted[0], 5), "kernel_ms_median": round(ms_sorted[len(ms_sorted) // 2], 5)}
-        if traffic is None:
-            print(f"bench.py: roofline.traffic is null: {note}", file=sys.stderr)
-        return rec
-
-    if world == 1 and not args.no_general and variant in index_skipping:
-        general = roofline_record(g_mean, gms, gv)
-
+    # what the communicator itself reports: every rank contributes its device to one all-gather
+    mine = torch.tensor([dev_index], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+    seen = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(seen, mine)
+    rccl = {"world": dist.get_world_size(), "backend": dist.get_backend(), "ranks_seen": len(seen),
+            "devices_of_ranks": [int(v.item()) for v in seen],
+            "version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None}
+    b_alg = algorithmic_bytes(rows, rows, nnz, vbytes)        # one launch group, this GPU's slab
+    key = f"{args.format}/{args.matrix}/{n}/{args.dtype}/gpus{world}/variant{variant}"
+    out = None
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         gflops = 2.0 * global_nnz / (ms_per_step * 1e-3) / 1e9
@@ -514,19 +773,22 @@ def main(argv=None):
             "config": {"workload": workload, "format": args.format,
                        "params": {"C": 64, "sigma": args.sigma} if fmt == S.SELL else {"p0": p0},
                        "rows": global_rows, "nnz": global_nnz, "stored_per_gpu": int(stored), "kernel_variant": variant,
-                       "exchange": args.exchange if world > 1 else None},
-            "roofline": roofline_record(mean_kernel_ms, kernel_ms, variant),
+                       "exchange": args.exchange},
+            "roofline": roofline_record(b_alg, mean_kernel_ms, kernel_ms, key, variant),
+            "rccl": rccl,
         }
-        if general is not None:
-            out["roofline"]["general"] = general
         if comm is not None:
             comm["exposed_ms"] = round(max(ms_per_step - comm["local_products_alone_ms"], 0.0), 5)
             out["communication"] = comm
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_n)
+    # the ranks are done: release the GPUs, then (rank 0) the same slabs from one process through the C ABI
+    del op, x, y
+    torch.cuda.empty_cache()
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        if not args.no_one_process:
+            out["c_abi_one_process"] = one_process_leg(argv, world)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
     return 0
 
 

@@ -253,6 +253,9 @@ typedef struct spmv_hip_rowblock_info {
  * rule of csr_bal.c:83-85 on rows) moved to the nearest multiple of `snap` rows
  * (1024 keeps SELL sorting windows and slices inside one block).  Host arrays. */
 int spmv_hip_partition_rows(int rows, const int *row_ptr, int parts, int snap, int *bounds);
+/* The same rule on 64-bit row pointers, for matrices whose non-zeros outgrow the
+ * reference's `int` counts (spmv.h:41-47) and exist only as per-GPU shards. */
+int spmv_hip_partition_rows64(int rows, const int64_t *row_ptr, int parts, int snap, int *bounds);
 
 /* Builds a block on the current device from its CSR in HBM (row pointers local to
  * the block, GLOBAL column indices, dtype values); the arrays are only read.
@@ -262,9 +265,14 @@ spmv_hip_rowblock *spmv_hip_rowblock_create(int format, int rows, int row_begin,
                                             int64_t p0, int64_t p1, void *stream);
 int spmv_hip_rowblock_free(spmv_hip_rowblock *rb);
 int spmv_hip_rowblock_get_info(const spmv_hip_rowblock *rb, spmv_hip_rowblock_info *info);
-/* "exact_order" as for spmv_hip_set_option, applied to the interior matrix (the
- * kernel trial is repeated under the restriction) */
+/* "exact_order" as for spmv_hip_set_option, applied to the interior and the
+ * boundary matrix.  A new block runs each matrix's default kernel (no trial has run
+ * yet), so setting the option before the first spmv_hip_rowblock_analyze pins the
+ * bits of y whatever the trials measure later. */
 int spmv_hip_rowblock_set_option(spmv_hip_rowblock *rb, const char *name, int64_t value);
+/* spmv_hip_analyze on the interior and on the boundary matrix (sellcs_analyze_matrix,
+ * sell.c:30, for both pieces of the block) */
+int spmv_hip_rowblock_analyze(spmv_hip_rowblock *rb, int reps);
 /* columns[0..halo): the remote columns, ascending (host array) */
 int spmv_hip_rowblock_halo_columns(const spmv_hip_rowblock *rb, int *columns);
 /* The local x entries (indices into x_local) other blocks need from this one, in
@@ -272,30 +280,70 @@ int spmv_hip_rowblock_halo_columns(const spmv_hip_rowblock *rb, int *columns);
  * d_send[k] = d_x[local_index[k]]. */
 int spmv_hip_rowblock_set_send_list(spmv_hip_rowblock *rb, int count, const int *local_index);
 int spmv_hip_rowblock_pack(spmv_hip_rowblock *rb, const void *d_x, void *d_send, void *stream);
+/* The same gather delivered in one launch: the send list is cut into `nseg` (at most
+ * 16) consecutive segments, segment s = entries seg_begin[s] .. seg_begin[s+1]-1
+ * (seg_begin[0] = 0, seg_begin[nseg] = the list's length), and entry k of segment s
+ * is stored to dst[s][k - seg_begin[s]].  dst[s] may be memory of another GPU that
+ * this block's device has peer access to: the halo then crosses xGMI as the
+ * kernel's own stores, without a copy per consumer. */
+int spmv_hip_rowblock_push(spmv_hip_rowblock *rb, const void *d_x, int nseg, const int *seg_begin, void *const *dst,
+                           void *stream);
 /* y[0..rows) = interior rows * d_x[0..rows); boundary rows receive 0 here and their
  * value from mult_boundary, which must follow on the same stream once
  * d_x_ext[rows..rows+halo) holds the halo. */
 int spmv_hip_rowblock_mult_interior(spmv_hip_rowblock *rb, const void *d_x, void *d_y, void *stream);
 int spmv_hip_rowblock_mult_boundary(spmv_hip_rowblock *rb, const void *d_x_ext, void *d_y, void *stream);
 
-/* All blocks driven by ONE host thread (reference threading model: the driver is
- * single-threaded, driver_spmv.c:112-347): the matrix is cut with
- * spmv_hip_partition_rows into `ngpus` blocks, block p built on devices[p]
- * (NULL = devices 0..ngpus-1; a device may be named more than once), each with a
- * compute and a communication stream.  One product packs the halo entries on every
- * block, pushes them to their consumers with peer-to-peer copies (xGMI) on the
- * communication streams while the interior products run, then multiplies the
- * boundary rows.  Sorts the caller's coo in place like the other creators. */
+/* All blocks of one process behind one handle, called from ONE host thread
+ * (reference threading model: the driver is single-threaded,
+ * driver_spmv.c:112-347): the matrix is cut with spmv_hip_partition_rows into
+ * `ngpus` blocks, block p built on devices[p] (NULL = devices 0..ngpus-1; a device
+ * may be named more than once), each with a compute and a communication stream.
+ * One product gathers the halo entries on every block and stores them straight into
+ * their consumers' vectors over xGMI (one kernel per block on its communication
+ * stream: spmv_hip_rowblock_push; pack + one peer-to-peer copy per consumer where a
+ * pair of GPUs has no peer access, or with SPMV_DIST_DIRECT_PUSH=0) while the
+ * interior products run, then multiplies the boundary rows.  So that the launches
+ * of the blocks are issued side by side and not one block after the other, the
+ * handle keeps one helper thread per block, hidden from the caller and asleep
+ * between calls (SPMV_DIST_THREADS=0 in the environment issues everything from the
+ * calling thread instead).  Every block starts on its default kernels:
+ * spmv_hip_dist_set_option("exact_order"), then spmv_hip_dist_analyze tune them.
+ * A pair of GPUs without peer access makes the runtime stage that pair's pushes
+ * through host memory: creation warns on stderr, spmv_hip_dist_get_peer_access
+ * reports it, and SPMV_REQUIRE_P2P=1 in the environment makes creation fail
+ * instead.  Sorts the caller's coo in place like the other creators. */
 spmv_hip_dist *spmv_hip_dist_create(int format, int rows, int columns, int nnz, struct mtx *coo, int dtype, int64_t p0,
                                     int64_t p1, int ngpus, const int *devices);
+/* The same handle over blocks the caller has built with spmv_hip_rowblock_create,
+ * each on the device it is to run on -- for matrices that never exist as one host
+ * COO: with more than 2^31 - 1 non-zeros in all (the reference's `int nnz`,
+ * spmv.h:26,41-47, cannot count them; every block still holds fewer), or generated
+ * shard by shard in HBM.  blocks[0..ngpus) must tile the square matrix in order
+ * (block p begins at the row where block p-1 ends; the last ends at
+ * columns_global) and share one dtype.  On success the handle owns the blocks
+ * (spmv_hip_dist_free frees them); on failure they stay the caller's. */
+spmv_hip_dist *spmv_hip_dist_create_from_blocks(int ngpus, spmv_hip_rowblock **blocks);
 /* mult_X with host vectors (driver_spmv.c:276) */
 int spmv_hip_dist_mult(spmv_hip_dist *d, const double *x, double *y);
 /* the timed power loop (driver_spmv.c:292-308) over all blocks: exchange + products
  * timed on the host clock from the first launch to the last block's completion,
- * x = y / ||y||_2 (norm over all blocks) untimed */
+ * x = y / ||y||_2 untimed (every block reduces its part of y on its own GPU; the
+ * partial norms meet in pinned host memory and are added in block order) */
 int spmv_hip_dist_bench(spmv_hip_dist *d, int min_iters, double min_seconds, double *x, int *iters, double *seconds);
+/* Measurement aid for the layer itself: `products` products on whatever x the blocks
+ * hold; *issue_seconds = host time until all launches of a product are issued (the
+ * part that one thread per GPU shortens), *total_seconds = until the last block has
+ * finished, both summed over the products.  No reference counterpart. */
+int spmv_hip_dist_issue_time(spmv_hip_dist *d, int products, double *issue_seconds, double *total_seconds);
 /* spmv_hip_rowblock_set_option on every block */
 int spmv_hip_dist_set_option(spmv_hip_dist *d, const char *name, int64_t value);
+/* spmv_hip_rowblock_analyze on every block (the blocks' trials run side by side) */
+int spmv_hip_dist_analyze(spmv_hip_dist *d, int reps);
+/* access[q * ngpus + p]: how the halo entries block q sends to block p travel --
+ * 2 = both blocks sit on one device, 1 = direct peer-to-peer write (peer access from
+ * q's device to p's is enabled), 0 = staged through host memory by the runtime. */
+int spmv_hip_dist_get_peer_access(const spmv_hip_dist *d, int *access);
 /* ngpus, bounds[0..ngpus], blocks[0..ngpus) -- any of them may be NULL */
 int spmv_hip_dist_get_info(const spmv_hip_dist *d, int *ngpus, int *bounds, spmv_hip_rowblock_info *blocks);
 int spmv_hip_dist_free(spmv_hip_dist *d);

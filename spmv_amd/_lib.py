@@ -72,16 +72,23 @@ SIGNATURES = {
     "spmv_hip_get_info": (_i, [_vp, C.POINTER(Info)]),
     "spmv_hip_download": (_i, [_vp, _i, _vp, C.c_size_t]),
     "spmv_hip_partition_rows": (_i, [_i, _vp, _i, _i, _vp]),
+    "spmv_hip_partition_rows64": (_i, [_i, _vp, _i, _i, _vp]),
     "spmv_hip_rowblock_create": (_vp, [_i, _i, _i, _i, _i64, _vp, _vp, _vp, _i, _i64, _i64, _vp]),
     "spmv_hip_rowblock_free": (_i, [_vp]),
     "spmv_hip_rowblock_get_info": (_i, [_vp, C.POINTER(RowBlockInfo)]),
     "spmv_hip_rowblock_set_option": (_i, [_vp, C.c_char_p, _i64]),
+    "spmv_hip_rowblock_analyze": (_i, [_vp, _i]),
     "spmv_hip_rowblock_halo_columns": (_i, [_vp, _vp]),
     "spmv_hip_rowblock_set_send_list": (_i, [_vp, _i, _vp]),
     "spmv_hip_rowblock_pack": (_i, [_vp, _vp, _vp, _vp]),
+    "spmv_hip_rowblock_push": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "spmv_hip_rowblock_mult_interior": (_i, [_vp, _vp, _vp, _vp]),
     "spmv_hip_rowblock_mult_boundary": (_i, [_vp, _vp, _vp, _vp]),
     "spmv_hip_dist_create": (_vp, [_i, _i, _i, _i, _vp, _i, _i64, _i64, _i, _vp]),
+    "spmv_hip_dist_create_from_blocks": (_vp, [_i, _vp]),
+    "spmv_hip_dist_analyze": (_i, [_vp, _i]),
+    "spmv_hip_dist_issue_time": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "spmv_hip_dist_get_peer_access": (_i, [_vp, _vp]),
     "spmv_hip_dist_mult": (_i, [_vp, _vp, _vp]),
     "spmv_hip_dist_bench": (_i, [_vp, _i, C.c_double, _vp, C.POINTER(_i), C.POINTER(C.c_double)]),
     "spmv_hip_dist_set_option": (_i, [_vp, C.c_char_p, _i64]),

@@ -14,9 +14,12 @@
  * SPMV_EXACT_ORDER=0 lets the kernel trial also pick variants that reassociate the
  * row sums (default: only variants whose y has the same bits run to run).
  * SPMV_NGPUS=n (n > 1) cuts every matrix into n row blocks of equal nnz shares, one
- * per GPU, driven from this one thread (spmv_hip_dist_*); SPMV_DEVICES="0,1,.."
- * names the devices (default 0..n-1; a device may repeat).  The CSV carries the
- * count in its NGPUs column.
+ * per GPU, driven from this one thread (spmv_hip_dist_*; the library issues the blocks'
+ * launches from a hidden helper thread per GPU); SPMV_DEVICES="0,1,.." names the
+ * devices (default 0..n-1; a device may repeat).  The CSV carries the count in its
+ * NGPUs column; one line after the table header says which pairs of GPUs exchange
+ * their halo directly and which through host memory (SPMV_REQUIRE_P2P=1 refuses the
+ * latter).  MODE auto picks a format per matrix on one GPU and is refused with n > 1.
  * Per matrix of LIST the driver
  *   1. estimates the memory need like enought_memory (driver_spmv.c:50-110;
  *      .bin headers are read as binary here -- the reference parses them as text),
@@ -84,6 +87,23 @@ static int has_suffix(const char *s, const char *suffix)
 }
 
 static int g_ngpus = 1;
+static int g_devices[64];
+
+/* Free HBM over the distinct devices of the run, in MB (0 = unknown). */
+static double free_hbm_mb(void)
+{
+    double total = 0.0;
+    for (int p = 0; p < g_ngpus; p++) {
+        int seen = 0;
+        for (int q = 0; q < p; q++) seen |= g_devices[q] == g_devices[p];
+        if (seen) continue;
+        size_t hbm_free = 0;
+        if (spmv_hip_init(g_devices[p]) || spmv_hip_mem_info(&hbm_free, NULL)) { total = 0.0; break; }
+        total += (double)(hbm_free / (1024 * 1024));
+    }
+    (void)spmv_hip_init(g_devices[0]);
+    return total;
+}
 
 /* Sizes from the file header, and the reference's estimate 2*16*nnz + 8*(rows+cols) bytes in MB. */
 static int enough_memory(const char *path, long *rows, long *cols, long *nnz, unsigned long *need_mb)
@@ -110,9 +130,8 @@ static int enough_memory(const char *path, long *rows, long *cols, long *nnz, un
     if (!(*need_mb < free_mb * 0.95)) return 0;
     /* the device holds the CSR arrays and the format built from them at the same time: about the same
      * 2 * 16 bytes per entry, against what is free in HBM (all GPUs of a row-block run together) */
-    size_t hbm_free = 0;
-    if (spmv_hip_mem_info(&hbm_free, NULL) == 0 && hbm_free > 0)
-        return (double)*need_mb < (double)(hbm_free / (1024 * 1024)) * 0.95 * g_ngpus;
+    const double hbm_mb = free_hbm_mb();
+    if (hbm_mb > 0.0) return (double)*need_mb < hbm_mb * 0.95;
     return 1;
 }
 
@@ -202,8 +221,8 @@ int main(int argc, char *argv[])
     int ngpus = getenv("SPMV_NGPUS") ? atoi(getenv("SPMV_NGPUS")) : 1;
     if (ngpus < 1 || ngpus > 64) { printf("Error: SPMV_NGPUS must be in 1..64\n"); exit(-1); }
     g_ngpus = ngpus;
-    int devices[64];
-    for (int p = 0; p < 64; p++) devices[p] = p;
+    int *devices = g_devices;
+    for (int p = 0; p < 64; p++) devices[p] = ngpus > 1 ? p : 0;
     if (getenv("SPMV_DEVICES")) {
         char list[256];
         snprintf(list, sizeof list, "%s", getenv("SPMV_DEVICES"));
@@ -212,11 +231,19 @@ int main(int argc, char *argv[])
         if (p < ngpus) { printf("Error: SPMV_DEVICES names %d devices, SPMV_NGPUS is %d\n", p, ngpus); exit(-1); }
     }
     const int vbytes = dtype == SPMV_HIP_F32 ? 4 : 8;
+    if (ngpus > 1) {                                       /* before any file is opened or written */
+        if (!strcmp(mode, "auto")) {
+            printf("Error: MODE auto picks a format per matrix on one GPU; with SPMV_NGPUS > 1 name the format.\n");
+            exit(-1);
+        }
+        long p0, p1;
+        (void)format_for_mode(mode, sigma, &p0, &p1);      /* exits on an unknown MODE */
+    }
     FILE *infd = fopen(argv[2], "r");
     if (!infd) { perror("Error openning file input for matrix list.\n"); exit(-1); }
     FILE *outfd = fopen(argv[3], "w");
     if (!outfd) { perror(argv[3]); exit(-1); }
-    if (spmv_hip_init(0)) die("spmv_hip_init");
+    if (spmv_hip_init(devices[0])) die("spmv_hip_init");
 
     fprintf(outfd, "Format;File;Rows;Columns;NNZ;GFlops;Time(s);GB/s;PctHBMPeak;Dtype;Variant;NGPUs\n");
     printf("\n  Format: %s   dtype: %s   GPUs: %d   list: %s   csv: %s\n\n", mode, dtype == SPMV_HIP_F32 ? "f32" : "f64", ngpus, argv[2], argv[3]);
@@ -224,6 +251,7 @@ int main(int argc, char *argv[])
            "T(s)", "Mem (Mb)", "GB/s", "%HBM", "ERROR", "Test");
 
     char line[MAX_PATH_LEN];
+    int peers_printed = 0;
     while (fgets(line, sizeof line, infd)) {
         line[strcspn(line, "\r\n")] = 0;
         if (!line[0]) continue;
@@ -252,7 +280,19 @@ int main(int argc, char *argv[])
             const int format = format_for_mode(mode, sigma, &p0, &p1);
             dist = spmv_hip_dist_create(format, rows, columns, nnz, coo, dtype, p0, p1, ngpus, devices);
             if (!dist) die("dist_create");
+            /* a new handle runs its default kernels: restrict the trial first, then tune */
             if (spmv_hip_dist_set_option(dist, "exact_order", exact_order)) die("dist_set_option");
+            if (spmv_hip_dist_analyze(dist, 3)) die("dist_analyze");
+            if (!peers_printed) {
+                int access[64 * 64], staged = 0, direct = 0;
+                if (spmv_hip_dist_get_peer_access(dist, access)) die("dist_get_peer_access");
+                for (int q = 0; q < ngpus; q++)
+                    for (int p = 0; p < ngpus; p++)
+                        if (p != q) { staged += access[q * ngpus + p] == 0; direct += access[q * ngpus + p] == 1; }
+                printf("  halo exchange: %d pairs peer-to-peer, %d pairs through host memory, %d pairs on one device\n",
+                       direct, staged, ngpus * (ngpus - 1) - direct - staged);
+                peers_printed = 1;
+            }
         } else {
             m = create_for_mode(mode, rows, columns, nnz, coo, dtype, sigma);
             if (!m) die("create");

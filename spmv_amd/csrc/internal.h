@@ -142,10 +142,14 @@ int launch_mult_mv(const spmv_hip_matrix *m, int n, const void *d_x, int64_t ldx
 int variant_candidates(const spmv_hip_matrix *m, int *out, int max_out);
 bool candidate_keeps_bits(const spmv_hip_matrix *m, int candidate);
 int launch_norm2(int n, const void *d_x, int dtype, double *d_out, hipStream_t stream);
+constexpr int kNormBlocks = 1024;                    // partial sums of the two-pass norm
+// the norm with the caller's own scratch of kNormBlocks doubles (handles that own streams keep one per stream)
+int launch_norm2_with(double *partial, int n, const void *d_x, int dtype, double *d_out, hipStream_t stream);
 constexpr int64_t kNormStaticMax = 0x7fffffffLL;     // elements spmv_hip_norm2_dev_noalloc accepts
 int static_scratch_setup();                          // current device's copy of the built-in scratch array
 int launch_norm2_static(int64_t n, const void *d_x, int dtype, double *d_out, hipStream_t stream);
 int launch_scale(int n, const void *d_y, void *d_x, int dtype, const double *d_norm, hipStream_t stream);
+int launch_scale_value(int n, const void *d_y, void *d_x, int dtype, double norm, hipStream_t stream);
 
 // api.hip -- a handle over CSR arrays already in HBM; own = the handle frees them (also when the
 // creation fails), otherwise they stay the caller's

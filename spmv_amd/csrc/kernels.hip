@@ -1106,8 +1106,6 @@ __global__ __launch_bounds__(kWave * W) void wave_tile_hot_kernel(const int *__r
 
 // -------------------------------------------------------------- vector ops --
 
-constexpr int kNormBlocks = 1024;
-
 template <typename T>
 __global__ __launch_bounds__(kBlock) void sumsq_partial_kernel(int n, const T *__restrict__ x,
                                                                double *__restrict__ partial)
@@ -1141,6 +1139,14 @@ __global__ __launch_bounds__(kBlock) void scale_kernel(int n, const T *__restric
                                                        const double *__restrict__ norm)
 {
     const double nrm = norm[0];
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        x[i] = (T)((double)y[i] / nrm);
+}
+
+// the same with the norm handed over by value (the row-block layer sums the blocks' norms on the host)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void scale_value_kernel(int n, const T *__restrict__ y, T *__restrict__ x, double nrm)
+{
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
         x[i] = (T)((double)y[i] / nrm);
 }
@@ -1714,7 +1720,7 @@ static double *norm_scratch(hipStream_t st)
     return p;
 }
 
-static int launch_norm2_with(double *partial, int n, const void *d_x, int dtype, double *d_out, hipStream_t st)
+int launch_norm2_with(double *partial, int n, const void *d_x, int dtype, double *d_out, hipStream_t st)
 {
     // every launch writes partial[0..blocks) before the second kernel reads exactly that range, so
     // whatever an earlier, larger call left behind is never read
@@ -1786,6 +1792,18 @@ int launch_scale(int n, const void *d_y, void *d_x, int dtype, const double *d_n
         hipLaunchKernelGGL((scale_kernel<float>), dim3(blocks), dim3(kBlock), 0, st, n, (const float *)d_y, (float *)d_x, d_norm);
     else
         hipLaunchKernelGGL((scale_kernel<double>), dim3(blocks), dim3(kBlock), 0, st, n, (const double *)d_y, (double *)d_x, d_norm);
+    SPMV_HIP_TRY(hipGetLastError(), return 1);
+    return 0;
+}
+
+int launch_scale_value(int n, const void *d_y, void *d_x, int dtype, double norm, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    int blocks = (int)std::min<int64_t>(2048, cdiv(n, kBlock));
+    if (dtype == SPMV_HIP_F32)
+        hipLaunchKernelGGL((scale_value_kernel<float>), dim3(blocks), dim3(kBlock), 0, st, n, (const float *)d_y, (float *)d_x, norm);
+    else
+        hipLaunchKernelGGL((scale_value_kernel<double>), dim3(blocks), dim3(kBlock), 0, st, n, (const double *)d_y, (double *)d_x, norm);
     SPMV_HIP_TRY(hipGetLastError(), return 1);
     return 0;
 }

@@ -17,18 +17,26 @@
 // three scans, one fill pass, a radix sort + unique of the remote columns.
 //
 // spmv_hip_rowblock_* is the per-GPU piece an exchange layer drives (one process per GPU over
-// RCCL: spmv_amd/distributed.py).  spmv_hip_dist_* drives all blocks from one host thread, one
-// stream pair per GPU, the halo pushed by peer-to-peer copies over xGMI while the interior
-// products run -- what the C driver uses.
+// RCCL: spmv_amd/distributed.py).  spmv_hip_dist_* drives all blocks of one process: the caller's
+// one thread hands every product to a helper thread per GPU (hidden inside the handle), each of
+// which issues its own block's launches on a stream pair, the halo pushed by peer-to-peer copies
+// over xGMI while the interior products run -- what the C driver uses.
 
 #include "internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -139,6 +147,28 @@ __global__ __launch_bounds__(256) void rb_pack_kernel(int n, const int *__restri
     if (k < n) out[k] = x[index[k]];
 }
 
+// The send list gathered and delivered in one launch: entry k of segment s (the entries seg_begin[s] ..
+// seg_begin[s+1]-1 of the list, all for one consumer) is stored to dst[s][k - seg_begin[s]] -- memory of the
+// consumer's GPU when peer access is enabled, so the halo crosses xGMI as the kernel's own stores and no copy
+// engine has to be programmed per consumer and product.
+constexpr int kMaxPushSegments = 16;
+struct push_plan {
+    int nseg;
+    int seg_begin[kMaxPushSegments + 1];
+    void *dst[kMaxPushSegments];
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void rb_push_kernel(int n, const int *__restrict__ index, const T *__restrict__ x,
+                                                      push_plan plan)
+{
+    const int k = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (k >= n) return;
+    int s = 0;
+    while (s + 1 < plan.nseg && k >= plan.seg_begin[s + 1]) s++;
+    ((T *)plan.dst[s])[k - plan.seg_begin[s]] = x[index[k]];
+}
+
 // sorted unique values of d_in[0..n) -> *d_out (hipMalloc'ed), *count
 static int sort_unique(const int *d_in, int64_t n, int **d_out, int *count, hipStream_t st)
 {
@@ -228,7 +258,6 @@ static int build_rowblock(spmv_hip_rowblock *rb, const int *d_row_ptr, const int
                                         /*own=*/true, st);
         d_irp = nullptr; icol = nullptr; ival = nullptr;       // freed with (or by the failed creation of) the handle
         if (!rb->interior) break;
-        if (spmv_hip_analyze(rb->interior, 3)) break;
         if (rb->boundary_rows > 0) {
             const bool exact_family = rb->format == SPMV_HIP_CSR_SCALAR || rb->format == SPMV_HIP_SELL ||
                                       rb->format == SPMV_HIP_SELLP || rb->format == SPMV_HIP_ELL ||
@@ -237,8 +266,6 @@ static int build_rowblock(spmv_hip_rowblock *rb, const int *d_row_ptr, const int
                                             bcol, bval, rb->dtype, 0, 0, /*own=*/true, st);
             brp = nullptr; bcol = nullptr; bval = nullptr;
             if (!rb->boundary) break;
-            // the kernel trial writes y[0..boundary_rows): run it before the row map points elsewhere
-            if (spmv_hip_analyze(rb->boundary, 3)) break;
             if (spmv_hip_set_row_map(rb->boundary, rb->d_bnd_rows)) break;
         }
         rc = 0;
@@ -250,11 +277,9 @@ static int build_rowblock(spmv_hip_rowblock *rb, const int *d_row_ptr, const int
     return rc;
 }
 
-} // namespace spmv
-
-extern "C" {
-
-int spmv_hip_partition_rows(int rows, const int *row_ptr, int parts, int snap, int *bounds)
+// block p ends at the first row whose row_ptr reaches (p+1)*nnz/parts, moved to the nearest multiple of snap
+template <typename P>
+static int partition_rows_impl(int rows, const P *row_ptr, int parts, int snap, int *bounds)
 {
     clear_error();
     if (rows < 0 || parts < 1 || !row_ptr || !bounds) { set_error("partition_rows: bad argument"); return 1; }
@@ -262,14 +287,27 @@ int spmv_hip_partition_rows(int rows, const int *row_ptr, int parts, int snap, i
     const int64_t nnz = row_ptr[rows];
     bounds[0] = 0;
     for (int p = 1; p < parts; p++) {
-        const int64_t target = nnz * p / parts;
-        // first row whose row_ptr reaches the target, moved to the nearest multiple of snap
-        int64_t c = std::lower_bound(row_ptr, row_ptr + rows + 1, target, [](int v, int64_t t) { return v < t; }) - row_ptr;
+        const int64_t target = (int64_t)((__int128)nnz * p / parts);
+        int64_t c = std::lower_bound(row_ptr, row_ptr + rows + 1, target, [](P v, int64_t t) { return (int64_t)v < t; }) - row_ptr;
         c = (c + snap / 2) / snap * snap;
         bounds[p] = (int)std::min<int64_t>(std::max<int64_t>(c, bounds[p - 1]), rows);
     }
     bounds[parts] = rows;
     return 0;
+}
+
+} // namespace spmv
+
+extern "C" {
+
+int spmv_hip_partition_rows(int rows, const int *row_ptr, int parts, int snap, int *bounds)
+{
+    return partition_rows_impl(rows, row_ptr, parts, snap, bounds);
+}
+
+int spmv_hip_partition_rows64(int rows, const int64_t *row_ptr, int parts, int snap, int *bounds)
+{
+    return partition_rows_impl(rows, row_ptr, parts, snap, bounds);
 }
 
 spmv_hip_rowblock *spmv_hip_rowblock_create(int format, int rows, int row_begin, int columns_global, int64_t nnz,
@@ -340,8 +378,22 @@ int spmv_hip_rowblock_set_option(spmv_hip_rowblock *rb, const char *name, int64_
     clear_error();
     if (!rb || !name) { set_error("NULL argument"); return 1; }
     if (strcmp(name, "exact_order")) { set_error("rowblock: unknown option '%s'", name); return 1; }
-    // the kernel trial is repeated under the new restriction
-    if (spmv_hip_set_option(rb->interior, name, value) || spmv_hip_analyze(rb->interior, 3)) return 1;
+    if (spmv_hip_set_option(rb->interior, name, value)) return 1;
+    if (rb->boundary && spmv_hip_set_option(rb->boundary, name, value)) return 1;
+    return 0;
+}
+
+int spmv_hip_rowblock_analyze(spmv_hip_rowblock *rb, int reps)
+{
+    clear_error();
+    if (!rb) { set_error("NULL handle"); return 1; }
+    if (spmv_hip_analyze(rb->interior, reps)) return 1;
+    if (rb->boundary) {
+        // the kernel trial writes y[0..boundary_rows) of a vector of its own: it runs without the row map
+        if (spmv_hip_set_row_map(rb->boundary, nullptr)) return 1;
+        const int rc = spmv_hip_analyze(rb->boundary, reps);
+        if (spmv_hip_set_row_map(rb->boundary, rb->d_bnd_rows) || rc) return 1;
+    }
     return 0;
 }
 
@@ -393,6 +445,39 @@ int spmv_hip_rowblock_pack(spmv_hip_rowblock *rb, const void *d_x, void *d_send,
     return 0;
 }
 
+int spmv_hip_rowblock_push(spmv_hip_rowblock *rb, const void *d_x, int nseg, const int *seg_begin, void *const *dst,
+                           void *stream)
+{
+    if (!rb) { set_error("NULL handle"); return 1; }
+    if (rb->nsend == 0) return 0;
+    if (!d_x || !seg_begin || !dst || nseg < 1 || nseg > kMaxPushSegments) {
+        set_error("rowblock_push: needs 1..%d segments and their destinations", kMaxPushSegments);
+        return 1;
+    }
+    push_plan plan;
+    plan.nseg = nseg;
+    for (int k = 0; k <= nseg; k++) plan.seg_begin[k] = seg_begin[k];
+    for (int k = 0; k < nseg; k++) {
+        if (seg_begin[k + 1] < seg_begin[k] || !dst[k]) { set_error("rowblock_push: bad segment %d", k); return 1; }
+        plan.dst[k] = dst[k];
+    }
+    if (seg_begin[0] != 0 || seg_begin[nseg] != rb->nsend) {
+        set_error("rowblock_push: the segments cover %d..%d, the send list has %d entries", seg_begin[0], seg_begin[nseg], rb->nsend);
+        return 1;
+    }
+    DeviceGuard on(rb->device);
+    if (!on.ok) return 1;
+    const dim3 grid(blocks_for(rb->nsend)), block(256);
+    if (rb->dtype == SPMV_HIP_F32)
+        hipLaunchKernelGGL(rb_push_kernel<float>, grid, block, 0, (hipStream_t)stream, rb->nsend, rb->d_send_index,
+                           (const float *)d_x, plan);
+    else
+        hipLaunchKernelGGL(rb_push_kernel<double>, grid, block, 0, (hipStream_t)stream, rb->nsend, rb->d_send_index,
+                           (const double *)d_x, plan);
+    SPMV_HIP_TRY(hipGetLastError(), return 1);
+    return 0;
+}
+
 int spmv_hip_rowblock_mult_interior(spmv_hip_rowblock *rb, const void *d_x, void *d_y, void *stream)
 {
     if (!rb) { set_error("NULL handle"); return 1; }
@@ -408,7 +493,21 @@ int spmv_hip_rowblock_mult_boundary(spmv_hip_rowblock *rb, const void *d_x_ext, 
 
 } // extern "C"
 
-// ------------------------------------------------ all blocks from one host thread --
+// ------------------------------------------------------ all blocks of one process --
+//
+// The caller is one host thread (the reference's driver is single-threaded,
+// driver_spmv.c:112-347).  Issuing every block's launches from that thread makes the host the
+// bottleneck as the blocks shrink (about ten asynchronous calls per block and product), so the
+// handle keeps one helper thread per block, bound to the block's device: a product is ONE command
+// that all helpers execute side by side, each issuing only its own block's sequence
+//     mark x -> interior product -> pack -> pushes to the consumers -> mark "sent"
+//     -> wait for the producers' "sent" marks -> boundary product.
+// The one cross-thread dependency inside a product -- a consumer may only wait on a producer's
+// "sent" event once that event has been recorded for THIS product -- is a per-block generation
+// counter the producer publishes after its hipEventRecord.  SPMV_DIST_THREADS=0 keeps everything
+// on the calling thread (same sequence, issued stage by stage over all blocks).
+
+enum { kOpNone = 0, kOpProduct, kOpSync, kOpProductSync, kOpNormScale, kOpAnalyze, kOpExit };
 
 struct spmv_hip_dist {
     int ngpus = 0, dtype = 0, rows = 0;
@@ -416,63 +515,255 @@ struct spmv_hip_dist {
     std::vector<int> device, bounds;                 // bounds: ngpus+1 row boundaries
     std::vector<spmv_hip_rowblock *> block;
     std::vector<char *> d_x, d_y, d_send;            // per block: [x_local | halo], y, packed entries for the others
-    std::vector<double *> d_norm;
+    std::vector<double *> d_norm, d_partial;         // per block: its norm and the partial sums of that reduction
+    double *h_norm = nullptr;                        // pinned: the blocks' norms, read by every helper
     std::vector<hipStream_t> compute, comm;
     std::vector<hipEvent_t> x_ready, sent;
     // block q sends block p the entries [send_off[q][p], send_off[q][p+1]) of its send buffer; they land at
     // halo position recv_off[p][q] of block p
     std::vector<std::vector<int>> send_off, recv_off;
+    // block q delivers its whole send list with one kernel (stores straight into the consumers' halo buffers)
+    // when every consumer is reachable by peer access and there are few enough of them: push_nseg[q] > 0
+    std::vector<int> push_nseg;
+    std::vector<std::vector<int>> push_begin;
+    std::vector<std::vector<void *>> push_dst;
+    // peer[q * ngpus + p]: how a push from block q to block p travels -- 2 same device, 1 direct peer-to-peer
+    // write (peer access enabled), 0 staged through host memory by the runtime
+    std::vector<int> peer;
+
+    // helper threads
+    bool threaded = false;
+    std::vector<std::thread> helper;
+    std::mutex mu;
+    std::condition_variable cv_cmd, cv_done;
+    std::atomic<uint64_t> seq{0};                    // command generation; `op` / `op_arg` are written before it moves
+    int op = kOpNone, op_arg = 0;
+    std::atomic<int> done{0}, failed{0}, norm_arrived{0};
+    std::unique_ptr<std::atomic<uint64_t>[]> sent_seq;   // per block: generation of its last recorded "sent" event
+    std::string error;                               // first failure of a command (under mu)
 };
 
 namespace spmv {
 
-static int dist_exchange_and_multiply(spmv_hip_dist *d)
+static inline void cpu_relax() { __builtin_ia32_pause(); }
+
+// Wait for `ready`: spin for the few microseconds a command or a neighbour normally takes, then sleep.
+template <class Pred> static void wait_for(Pred ready, std::mutex &mu, std::condition_variable &cv)
+{
+    for (int i = 0; i < 30000; i++) {
+        if (ready()) return;
+        cpu_relax();
+    }
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, ready);
+}
+
+static void wake(std::mutex &mu, std::condition_variable &cv)
+{
+    { std::lock_guard<std::mutex> lk(mu); }         // a sleeper is either before its check or already waiting
+    cv.notify_all();
+}
+
+static void dist_fail(spmv_hip_dist *d, const char *what)
+{
+    std::lock_guard<std::mutex> lk(d->mu);
+    if (!d->failed.load()) d->error = what && what[0] ? what : "dist: a device call failed";
+    d->failed.store(1);
+}
+
+// ---- the stages of one product, for block p (the block's device is current) ----
+
+static int stage_interior(spmv_hip_dist *d, int p)
+{
+    // x of this product is in place on the compute stream: mark it, then start the interior rows
+    SPMV_HIP_TRY(hipEventRecord(d->x_ready[p], d->compute[p]), return 1);
+    return spmv_hip_rowblock_mult_interior(d->block[p], d->d_x[p], d->d_y[p], d->compute[p]);
+}
+
+static int stage_push(spmv_hip_dist *d, int q)
 {
     const size_t es = dtype_size(d->dtype);
     const int P = d->ngpus;
-    // One host thread issues everything, so the order of issue matters: first every block's interior product
-    // (it needs no communication and is nearly all of the work), so that every GPU is busy within a few launch
-    // latencies; then, while those run, the packing and the pushes on the communication streams; last the
-    // boundary rows.
-    // 1. x of this product is in place on the compute stream: mark it, then start the interior rows
-    for (int p = 0; p < P; p++) {
-        SPMV_HIP_TRY(hipSetDevice(d->device[p]), return 1);
-        SPMV_HIP_TRY(hipEventRecord(d->x_ready[p], d->compute[p]), return 1);
-        if (spmv_hip_rowblock_mult_interior(d->block[p], d->d_x[p], d->d_y[p], d->compute[p])) return 1;
-    }
-    // 2. every block packs what the others need and pushes it to them on its communication stream
-    for (int q = 0; q < P; q++) {
-        SPMV_HIP_TRY(hipSetDevice(d->device[q]), return 1);
-        SPMV_HIP_TRY(hipStreamWaitEvent(d->comm[q], d->x_ready[q], 0), return 1);
-        if (spmv_hip_rowblock_pack(d->block[q], d->d_x[q], d->d_send[q], d->comm[q])) return 1;
-        for (int p = 0; p < P; p++) {
-            const int count = d->send_off[q][p + 1] - d->send_off[q][p];
-            if (p == q || count == 0) continue;
-            char *dst = d->d_x[p] + ((size_t)d->block[p]->rows + (size_t)d->recv_off[p][q]) * es;
-            const char *src = d->d_send[q] + (size_t)d->send_off[q][p] * es;
-            SPMV_HIP_TRY(hipMemcpyPeerAsync(dst, d->device[p], src, d->device[q], (size_t)count * es, d->comm[q]), return 1);
-        }
+    SPMV_HIP_TRY(hipStreamWaitEvent(d->comm[q], d->x_ready[q], 0), return 1);
+    if (d->push_nseg[q] > 0) {
+        if (spmv_hip_rowblock_push(d->block[q], d->d_x[q], d->push_nseg[q], d->push_begin[q].data(), d->push_dst[q].data(),
+                                   d->comm[q]))
+            return 1;
         SPMV_HIP_TRY(hipEventRecord(d->sent[q], d->comm[q]), return 1);
+        return 0;
     }
-    // 3. the boundary rows once every sender's pushes have landed
+    if (spmv_hip_rowblock_pack(d->block[q], d->d_x[q], d->d_send[q], d->comm[q])) return 1;
     for (int p = 0; p < P; p++) {
-        SPMV_HIP_TRY(hipSetDevice(d->device[p]), return 1);
-        for (int q = 0; q < P; q++)
-            if (q != p && d->send_off[q][p + 1] > d->send_off[q][p])
-                SPMV_HIP_TRY(hipStreamWaitEvent(d->compute[p], d->sent[q], 0), return 1);
-        if (spmv_hip_rowblock_mult_boundary(d->block[p], d->d_x[p], d->d_y[p], d->compute[p])) return 1;
+        const int count = d->send_off[q][p + 1] - d->send_off[q][p];
+        if (p == q || count == 0) continue;
+        char *dst = d->d_x[p] + ((size_t)d->block[p]->rows + (size_t)d->recv_off[p][q]) * es;
+        const char *src = d->d_send[q] + (size_t)d->send_off[q][p] * es;
+        SPMV_HIP_TRY(hipMemcpyPeerAsync(dst, d->device[p], src, d->device[q], (size_t)count * es, d->comm[q]), return 1);
     }
+    SPMV_HIP_TRY(hipEventRecord(d->sent[q], d->comm[q]), return 1);
     return 0;
 }
 
-static int dist_sync(spmv_hip_dist *d)
+// gen != 0: wait until every producer has recorded its "sent" event of command `gen` (helper threads)
+static int stage_boundary(spmv_hip_dist *d, int p, uint64_t gen)
 {
-    for (int p = 0; p < d->ngpus; p++) {
-        SPMV_HIP_TRY(hipSetDevice(d->device[p]), return 1);
-        SPMV_HIP_TRY(hipStreamSynchronize(d->comm[p]), return 1);
-        SPMV_HIP_TRY(hipStreamSynchronize(d->compute[p]), return 1);
+    for (int q = 0; q < d->ngpus; q++) {
+        if (q == p || d->send_off[q][p + 1] == d->send_off[q][p]) continue;
+        if (gen) {
+            while (d->sent_seq[q].load(std::memory_order_acquire) < gen) {
+                if (d->failed.load(std::memory_order_relaxed)) { set_error("dist: another block's exchange failed"); return 1; }
+                cpu_relax();
+            }
+        }
+        SPMV_HIP_TRY(hipStreamWaitEvent(d->compute[p], d->sent[q], 0), return 1);
     }
+    return spmv_hip_rowblock_mult_boundary(d->block[p], d->d_x[p], d->d_y[p], d->compute[p]);
+}
+
+static int stage_sync(spmv_hip_dist *d, int p)
+{
+    SPMV_HIP_TRY(hipStreamSynchronize(d->comm[p]), return 1);
+    SPMV_HIP_TRY(hipStreamSynchronize(d->compute[p]), return 1);
     return 0;
+}
+
+// ||y_p||_2 into the pinned slot p; the caller has the compute stream synchronised when this returns
+static int stage_norm(spmv_hip_dist *d, int p)
+{
+    if (launch_norm2_with(d->d_partial[p], d->block[p]->rows, d->d_y[p], d->dtype, d->d_norm[p], d->compute[p])) return 1;
+    SPMV_HIP_TRY(hipMemcpyAsync(&d->h_norm[p], d->d_norm[p], sizeof(double), hipMemcpyDeviceToHost, d->compute[p]), return 1);
+    SPMV_HIP_TRY(hipStreamSynchronize(d->compute[p]), return 1);
+    return 0;
+}
+
+// the norm over all blocks, summed in block order: the same bits in every helper
+static double dist_norm(const spmv_hip_dist *d)
+{
+    double sumsq = 0.0;
+    for (int q = 0; q < d->ngpus; q++) sumsq += d->h_norm[q] * d->h_norm[q];
+    return std::sqrt(sumsq);
+}
+
+static int stage_scale(spmv_hip_dist *d, int p, double norm)
+{
+    if (launch_scale_value(d->block[p]->rows, d->d_y[p], d->d_x[p], d->dtype, norm, d->compute[p])) return 1;
+    SPMV_HIP_TRY(hipStreamSynchronize(d->compute[p]), return 1);
+    return 0;
+}
+
+// ---- helper threads ----
+
+static int helper_execute(spmv_hip_dist *d, int p, int op, int arg, uint64_t gen)
+{
+    switch (op) {
+    case kOpProduct:
+    case kOpProductSync: {
+        int rc = stage_interior(d, p) || stage_push(d, p);
+        // published even after a failure, so that no consumer spins for it (they see `failed`)
+        if (rc) dist_fail(d, spmv_hip_last_error());
+        d->sent_seq[p].store(gen, std::memory_order_release);
+        if (rc) return 1;
+        if (stage_boundary(d, p, gen)) return 1;
+        return op == kOpProductSync ? stage_sync(d, p) : 0;
+    }
+    case kOpSync: return stage_sync(d, p);
+    case kOpNormScale: {
+        const int rc = stage_norm(d, p);
+        if (rc) dist_fail(d, spmv_hip_last_error());
+        d->norm_arrived.fetch_add(1, std::memory_order_acq_rel);
+        if (rc) return 1;
+        while (d->norm_arrived.load(std::memory_order_acquire) < d->ngpus) {
+            if (d->failed.load(std::memory_order_relaxed)) { set_error("dist: another block's norm failed"); return 1; }
+            cpu_relax();
+        }
+        if (d->failed.load()) { set_error("dist: another block's norm failed"); return 1; }
+        return stage_scale(d, p, dist_norm(d));
+    }
+    case kOpAnalyze: return spmv_hip_rowblock_analyze(d->block[p], arg);
+    default: return 0;
+    }
+}
+
+static void helper_main(spmv_hip_dist *d, int p)
+{
+    const bool have_device = hipSetDevice(d->device[p]) == hipSuccess;
+    uint64_t seen = 0;
+    for (;;) {
+        wait_for([&] { return d->seq.load(std::memory_order_acquire) != seen; }, d->mu, d->cv_cmd);
+        seen = d->seq.load(std::memory_order_acquire);
+        const int op = d->op, arg = d->op_arg;
+        if (op != kOpExit) {
+            clear_error();
+            int rc = 1;
+            if (have_device) rc = helper_execute(d, p, op, arg, seen);
+            else set_error("dist: hipSetDevice(%d) failed in the helper of block %d", d->device[p], p);
+            if (rc) dist_fail(d, spmv_hip_last_error());
+        }
+        d->done.fetch_add(1, std::memory_order_acq_rel);
+        wake(d->mu, d->cv_done);
+        if (op == kOpExit) return;
+    }
+}
+
+// One command to every block; returns when all of them have executed it.
+static int dist_run(spmv_hip_dist *d, int op, int arg = 0)
+{
+    const int P = d->ngpus;
+    if (d->threaded) {
+        d->done.store(0);
+        d->failed.store(0);
+        d->norm_arrived.store(0);
+        d->op = op;
+        d->op_arg = arg;
+        d->seq.fetch_add(1, std::memory_order_acq_rel);
+        wake(d->mu, d->cv_cmd);
+        wait_for([&] { return d->done.load(std::memory_order_acquire) == P; }, d->mu, d->cv_done);
+        if (d->failed.load()) {
+            std::lock_guard<std::mutex> lk(d->mu);
+            set_error("%s", d->error.c_str());
+            return 1;
+        }
+        return 0;
+    }
+    // the calling thread issues everything, stage by stage over all blocks: first every interior product
+    // (no communication, nearly all of the work), so that every GPU is busy within a few launch latencies;
+    // then the packing and the pushes on the communication streams; last the boundary rows
+    auto each = [&](auto stage) {
+        for (int p = 0; p < P; p++) {
+            SPMV_HIP_TRY(hipSetDevice(d->device[p]), return 1);
+            if (stage(p)) return 1;
+        }
+        return 0;
+    };
+    switch (op) {
+    case kOpProduct:
+    case kOpProductSync:
+        if (each([&](int p) { return stage_interior(d, p); }) || each([&](int p) { return stage_push(d, p); }) ||
+            each([&](int p) { return stage_boundary(d, p, 0); }))
+            return 1;
+        return op == kOpProductSync ? each([&](int p) { return stage_sync(d, p); }) : 0;
+    case kOpSync: return each([&](int p) { return stage_sync(d, p); });
+    case kOpNormScale: {
+        if (each([&](int p) { return stage_norm(d, p); })) return 1;
+        const double norm = dist_norm(d);
+        return each([&](int p) { return stage_scale(d, p, norm); });
+    }
+    case kOpAnalyze: return each([&](int p) { return spmv_hip_rowblock_analyze(d->block[p], arg); });
+    default: return 0;
+    }
+}
+
+static void dist_stop_helpers(spmv_hip_dist *d)
+{
+    if (!d->threaded) return;
+    d->done.store(0);
+    d->op = kOpExit;
+    d->seq.fetch_add(1, std::memory_order_acq_rel);
+    wake(d->mu, d->cv_cmd);
+    for (std::thread &t : d->helper)
+        if (t.joinable()) t.join();
+    d->helper.clear();
+    d->threaded = false;
 }
 
 static int dist_upload_x(spmv_hip_dist *d, const double *x)
@@ -508,6 +799,118 @@ static int dist_download(spmv_hip_dist *d, const std::vector<char *> &src, doubl
     return 0;
 }
 
+// Everything of a handle beyond its blocks: vectors, streams, events, peer access, who sends what, helpers.
+// d->device, d->bounds and d->block are in place.
+static int dist_finish(spmv_hip_dist *d)
+{
+    const int P = d->ngpus;
+    const size_t es = dtype_size(d->dtype);
+    d->d_x.assign(P, nullptr); d->d_y.assign(P, nullptr); d->d_send.assign(P, nullptr);
+    d->d_norm.assign(P, nullptr); d->d_partial.assign(P, nullptr);
+    d->compute.assign(P, nullptr); d->comm.assign(P, nullptr);
+    d->x_ready.assign(P, nullptr); d->sent.assign(P, nullptr);
+    d->peer.assign((size_t)P * P, 2);
+    SPMV_HIP_TRY(hipHostMalloc((void **)&d->h_norm, sizeof(double) * (size_t)P, hipHostMallocDefault), return 1);
+    std::vector<std::vector<int>> halo(P);
+    const char *require = getenv("SPMV_REQUIRE_P2P");
+    const bool require_p2p = require && atoi(require) != 0;
+    for (int q = 0; q < P; q++) {
+        SPMV_HIP_TRY(hipSetDevice(d->device[q]), return 1);
+        // pushes go from q's communication stream into p's memory: q needs access to p
+        for (int p = 0; p < P; p++) {
+            if (d->device[p] == d->device[q]) continue;
+            int can = 0, direct = 0;
+            if (hipDeviceCanAccessPeer(&can, d->device[q], d->device[p]) == hipSuccess && can) {
+                const hipError_t e = hipDeviceEnablePeerAccess(d->device[p], 0);
+                direct = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+            }
+            (void)hipGetLastError();
+            d->peer[(size_t)q * P + p] = direct;
+            if (!direct) {
+                if (require_p2p) {
+                    set_error("dist: GPU %d has no peer access to GPU %d (SPMV_REQUIRE_P2P is set)", d->device[q], d->device[p]);
+                    return 1;
+                }
+                fprintf(stderr, "spmv_hip: WARNING: GPU %d has no peer access to GPU %d: the halo of block %d travels to "
+                                "block %d through host memory, at PCIe speed (SPMV_REQUIRE_P2P=1 refuses this)\n",
+                        d->device[q], d->device[p], q, p);
+            }
+        }
+        const int n = d->block[q]->rows, nh = d->block[q]->halo;
+        halo[q].resize((size_t)nh);
+        if (spmv_hip_rowblock_halo_columns(d->block[q], halo[q].data())) return 1;
+        SPMV_HIP_TRY(hipMalloc((void **)&d->d_x[q], es * (size_t)std::max(n + nh, 1)), return 1);
+        SPMV_HIP_TRY(hipMemset(d->d_x[q], 0, es * (size_t)std::max(n + nh, 1)), return 1);
+        SPMV_HIP_TRY(hipMalloc((void **)&d->d_y[q], es * (size_t)std::max(n, 1)), return 1);
+        SPMV_HIP_TRY(hipMalloc((void **)&d->d_norm[q], sizeof(double)), return 1);
+        SPMV_HIP_TRY(hipMalloc((void **)&d->d_partial[q], sizeof(double) * kNormBlocks), return 1);
+        SPMV_HIP_TRY(hipStreamCreateWithFlags(&d->compute[q], hipStreamNonBlocking), return 1);
+        SPMV_HIP_TRY(hipStreamCreateWithFlags(&d->comm[q], hipStreamNonBlocking), return 1);
+        SPMV_HIP_TRY(hipEventCreateWithFlags(&d->x_ready[q], hipEventDisableTiming), return 1);
+        SPMV_HIP_TRY(hipEventCreateWithFlags(&d->sent[q], hipEventDisableTiming), return 1);
+    }
+    // who sends what: block p's halo is sorted by global column, so what it needs from owner q is one
+    // contiguous piece of it; q's send buffer holds the pieces for p = 0, 1, ... in that order
+    d->send_off.assign(P, std::vector<int>((size_t)P + 1, 0));
+    d->recv_off.assign(P, std::vector<int>((size_t)P + 1, 0));
+    std::vector<std::vector<int>> send_list(P);
+    for (int p = 0; p < P; p++)
+        for (int q = 0; q < P; q++) {
+            const auto first = std::lower_bound(halo[p].begin(), halo[p].end(), d->bounds[q]);
+            const auto last = std::lower_bound(halo[p].begin(), halo[p].end(), d->bounds[q + 1]);
+            d->recv_off[p][q] = (int)(first - halo[p].begin());
+            d->recv_off[p][q + 1] = (int)(last - halo[p].begin());
+        }
+    for (int q = 0; q < P; q++)
+        for (int p = 0; p < P; p++) {
+            d->send_off[q][p] = (int)send_list[q].size();
+            if (p != q)
+                for (int k = d->recv_off[p][q]; k < d->recv_off[p][q + 1]; k++) send_list[q].push_back(halo[p][(size_t)k] - d->bounds[q]);
+            d->send_off[q][p + 1] = (int)send_list[q].size();
+        }
+    d->push_nseg.assign(P, 0);
+    d->push_begin.assign(P, std::vector<int>());
+    d->push_dst.assign(P, std::vector<void *>());
+    const char *direct_env = getenv("SPMV_DIST_DIRECT_PUSH");
+    const bool direct_push = !direct_env || atoi(direct_env) != 0;
+    for (int q = 0; q < P; q++) {
+        SPMV_HIP_TRY(hipSetDevice(d->device[q]), return 1);
+        if (spmv_hip_rowblock_set_send_list(d->block[q], (int)send_list[q].size(), send_list[q].data())) return 1;
+        SPMV_HIP_TRY(hipMalloc((void **)&d->d_send[q], es * std::max<size_t>(send_list[q].size(), 1)), return 1);
+        // one store kernel instead of pack + a copy per consumer, where every consumer can be written directly
+        bool all_direct = direct_push;
+        std::vector<int> begin;
+        std::vector<void *> dst;
+        for (int p = 0; p < P && all_direct; p++) {
+            const int count = d->send_off[q][p + 1] - d->send_off[q][p];
+            if (p == q || count == 0) continue;
+            all_direct = d->peer[(size_t)q * P + p] != 0;
+            begin.push_back(d->send_off[q][p]);
+            dst.push_back(d->d_x[p] + ((size_t)d->block[p]->rows + (size_t)d->recv_off[p][q]) * es);
+        }
+        if (all_direct && !dst.empty() && (int)dst.size() <= kMaxPushSegments) {
+            begin.push_back((int)send_list[q].size());
+            d->push_nseg[q] = (int)dst.size();
+            d->push_begin[q] = begin;
+            d->push_dst[q] = dst;
+        }
+    }
+    const char *threads = getenv("SPMV_DIST_THREADS");
+    if (!threads || atoi(threads) != 0) {
+        d->sent_seq.reset(new std::atomic<uint64_t>[(size_t)P]);
+        for (int p = 0; p < P; p++) d->sent_seq[p].store(0);
+        d->threaded = true;
+        try {
+            for (int p = 0; p < P; p++) d->helper.emplace_back(helper_main, d, p);
+        } catch (...) {
+            dist_stop_helpers(d);
+            set_error("dist: could not start the helper threads");
+            return 1;
+        }
+    }
+    return 0;
+}
+
 } // namespace spmv
 
 extern "C" {
@@ -515,6 +918,7 @@ extern "C" {
 int spmv_hip_dist_free(spmv_hip_dist *d)
 {
     if (!d) return 0;
+    dist_stop_helpers(d);
     int prev = 0;
     const bool have_prev = hipGetDevice(&prev) == hipSuccess;
     for (int p = 0; p < (int)d->device.size(); p++) {
@@ -524,14 +928,27 @@ int spmv_hip_dist_free(spmv_hip_dist *d)
         if (p < (int)d->d_y.size() && d->d_y[p]) (void)hipFree(d->d_y[p]);
         if (p < (int)d->d_send.size() && d->d_send[p]) (void)hipFree(d->d_send[p]);
         if (p < (int)d->d_norm.size() && d->d_norm[p]) (void)hipFree(d->d_norm[p]);
+        if (p < (int)d->d_partial.size() && d->d_partial[p]) (void)hipFree(d->d_partial[p]);
         if (p < (int)d->compute.size() && d->compute[p]) (void)hipStreamDestroy(d->compute[p]);
         if (p < (int)d->comm.size() && d->comm[p]) (void)hipStreamDestroy(d->comm[p]);
         if (p < (int)d->x_ready.size() && d->x_ready[p]) (void)hipEventDestroy(d->x_ready[p]);
         if (p < (int)d->sent.size() && d->sent[p]) (void)hipEventDestroy(d->sent[p]);
     }
+    if (d->h_norm) (void)hipHostFree(d->h_norm);
     if (have_prev) (void)hipSetDevice(prev);
     delete d;
     return 0;
+}
+
+// on failure: frees the handle (and the blocks it holds unless `keep_blocks`), keeps the message
+static spmv_hip_dist *dist_abandon(spmv_hip_dist *d, bool keep_blocks)
+{
+    char keep[512];
+    snprintf(keep, sizeof keep, "%s", spmv_hip_last_error());
+    if (keep_blocks) std::fill(d->block.begin(), d->block.end(), nullptr);
+    spmv_hip_dist_free(d);
+    set_error("%s", keep);
+    return nullptr;
 }
 
 spmv_hip_dist *spmv_hip_dist_create(int format, int rows, int columns, int nnz, struct mtx *coo, int dtype, int64_t p0,
@@ -559,9 +976,7 @@ spmv_hip_dist *spmv_hip_dist_create(int format, int rows, int columns, int nnz, 
             return nullptr;
         }
     }
-    d->block.assign(P, nullptr); d->d_x.assign(P, nullptr); d->d_y.assign(P, nullptr); d->d_send.assign(P, nullptr);
-    d->d_norm.assign(P, nullptr); d->compute.assign(P, nullptr); d->comm.assign(P, nullptr);
-    d->x_ready.assign(P, nullptr); d->sent.assign(P, nullptr);
+    d->block.assign(P, nullptr);
     const size_t es = dtype_size(dtype);
     int rc = 1;
     do {
@@ -578,17 +993,9 @@ spmv_hip_dist *spmv_hip_dist_create(int format, int rows, int columns, int nnz, 
         d->bounds.resize((size_t)P + 1);
         // boundaries on multiples of 1024 rows: SELL sorting windows and slices never straddle two blocks
         if (spmv_hip_partition_rows(rows, rp.data(), P, 1024, d->bounds.data())) break;
-        std::vector<std::vector<int>> halo(P);
         for (int p = 0; p < P && ok; p++) {
             ok = false;
             SPMV_HIP_TRY(hipSetDevice(d->device[p]), break);
-            for (int q = 0; q < P; q++)
-                if (d->device[q] != d->device[p]) {
-                    int can = 0;
-                    if (hipDeviceCanAccessPeer(&can, d->device[p], d->device[q]) == hipSuccess && can)
-                        (void)hipDeviceEnablePeerAccess(d->device[q], 0);     // already enabled is fine
-                }
-            (void)hipGetLastError();
             const int b = d->bounds[p], e = d->bounds[p + 1], n = e - b;
             const int lo = rp[b], cnt = rp[e] - lo;
             std::vector<int> lrp((size_t)n + 1), lcol((size_t)std::max(cnt, 1));
@@ -618,57 +1025,55 @@ spmv_hip_dist *spmv_hip_dist_create(int format, int rows, int columns, int nnz, 
             if (d_col) (void)hipFree(d_col);
             if (d_val) (void)hipFree(d_val);
             if (!d->block[p]) break;
-            halo[p].resize((size_t)d->block[p]->halo);
-            if (spmv_hip_rowblock_halo_columns(d->block[p], halo[p].data())) break;
-            SPMV_HIP_TRY(hipMalloc((void **)&d->d_x[p], es * (size_t)std::max(n + d->block[p]->halo, 1)), break);
-            SPMV_HIP_TRY(hipMemset(d->d_x[p], 0, es * (size_t)std::max(n + d->block[p]->halo, 1)), break);
-            SPMV_HIP_TRY(hipMalloc((void **)&d->d_y[p], es * (size_t)std::max(n, 1)), break);
-            SPMV_HIP_TRY(hipMalloc((void **)&d->d_norm[p], sizeof(double)), break);
-            SPMV_HIP_TRY(hipStreamCreateWithFlags(&d->compute[p], hipStreamNonBlocking), break);
-            SPMV_HIP_TRY(hipStreamCreateWithFlags(&d->comm[p], hipStreamNonBlocking), break);
-            SPMV_HIP_TRY(hipEventCreateWithFlags(&d->x_ready[p], hipEventDisableTiming), break);
-            SPMV_HIP_TRY(hipEventCreateWithFlags(&d->sent[p], hipEventDisableTiming), break);
             ok = true;
         }
         if (!ok) break;
-        // who sends what: block p's halo is sorted by global column, so what it needs from owner q is one
-        // contiguous piece of it; q's send buffer holds the pieces for p = 0, 1, ... in that order
-        d->send_off.assign(P, std::vector<int>((size_t)P + 1, 0));
-        d->recv_off.assign(P, std::vector<int>((size_t)P + 1, 0));
-        std::vector<std::vector<int>> send_list(P);
-        for (int p = 0; p < P; p++)
-            for (int q = 0; q < P; q++) {
-                const auto first = std::lower_bound(halo[p].begin(), halo[p].end(), d->bounds[q]);
-                const auto last = std::lower_bound(halo[p].begin(), halo[p].end(), d->bounds[q + 1]);
-                d->recv_off[p][q] = (int)(first - halo[p].begin());
-                d->recv_off[p][q + 1] = (int)(last - halo[p].begin());
-            }
-        for (int q = 0; q < P; q++)
-            for (int p = 0; p < P; p++) {
-                d->send_off[q][p] = (int)send_list[q].size();
-                if (p != q)
-                    for (int k = d->recv_off[p][q]; k < d->recv_off[p][q + 1]; k++) send_list[q].push_back(halo[p][(size_t)k] - d->bounds[q]);
-                d->send_off[q][p + 1] = (int)send_list[q].size();
-            }
-        for (int q = 0; q < P && ok; q++) {
-            ok = false;
-            SPMV_HIP_TRY(hipSetDevice(d->device[q]), break);
-            if (spmv_hip_rowblock_set_send_list(d->block[q], (int)send_list[q].size(), send_list[q].data())) break;
-            SPMV_HIP_TRY(hipMalloc((void **)&d->d_send[q], es * std::max<size_t>(send_list[q].size(), 1)), break);
-            ok = true;
-        }
-        if (!ok) break;
+        if (dist_finish(d)) break;
         rc = 0;
     } while (0);
     (void)hipSetDevice(prev);
-    if (rc) {
-        char keep[512];
-        snprintf(keep, sizeof keep, "%s", spmv_hip_last_error());
-        spmv_hip_dist_free(d);
-        set_error("%s", keep);
+    return rc ? dist_abandon(d, false) : d;
+}
+
+spmv_hip_dist *spmv_hip_dist_create_from_blocks(int ngpus, spmv_hip_rowblock **blocks)
+{
+    clear_error();
+    if (ngpus < 1 || ngpus > 64 || !blocks) { set_error("dist: bad argument"); return nullptr; }
+    for (int p = 0; p < ngpus; p++)
+        if (!blocks[p]) { set_error("dist: block %d is NULL", p); return nullptr; }
+    const int columns = blocks[0]->columns_global;
+    int64_t nnz = 0;
+    for (int p = 0; p < ngpus; p++) {
+        const spmv_hip_rowblock *b = blocks[p];
+        const int64_t expect = p ? (int64_t)blocks[p - 1]->row_begin + blocks[p - 1]->rows : 0;
+        if (b->row_begin != expect || b->columns_global != columns || b->dtype != blocks[0]->dtype) {
+            set_error("dist: block %d (rows from %d, %d columns, dtype %d) does not continue the blocks before it (next row %lld, "
+                      "%d columns, dtype %d)", p, b->row_begin, b->columns_global, b->dtype, (long long)expect, columns,
+                      blocks[0]->dtype);
+            return nullptr;
+        }
+        nnz += b->nnz;
+    }
+    if ((int64_t)blocks[ngpus - 1]->row_begin + blocks[ngpus - 1]->rows != columns) {
+        set_error("dist: the blocks end at row %lld of %d", (long long)blocks[ngpus - 1]->row_begin + blocks[ngpus - 1]->rows, columns);
         return nullptr;
     }
-    return d;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    spmv_hip_dist *d = new (std::nothrow) spmv_hip_dist();
+    if (!d) { set_error("out of host memory"); return nullptr; }
+    d->ngpus = ngpus; d->dtype = blocks[0]->dtype; d->rows = columns; d->nnz = nnz;
+    d->device.resize(ngpus);
+    d->bounds.resize((size_t)ngpus + 1);
+    d->block.assign(blocks, blocks + ngpus);
+    for (int p = 0; p < ngpus; p++) {
+        d->device[p] = blocks[p]->device;
+        d->bounds[p] = blocks[p]->row_begin;
+    }
+    d->bounds[ngpus] = columns;
+    const int rc = dist_finish(d);
+    (void)hipSetDevice(prev);
+    return rc ? dist_abandon(d, true) : d;       // after a failure the blocks stay the caller's
 }
 
 int spmv_hip_dist_mult(spmv_hip_dist *d, const double *x, double *y)
@@ -677,7 +1082,7 @@ int spmv_hip_dist_mult(spmv_hip_dist *d, const double *x, double *y)
     if (!d || !x || !y) { set_error("NULL argument"); return 1; }
     int prev = 0;
     (void)hipGetDevice(&prev);
-    int rc = dist_upload_x(d, x) || dist_exchange_and_multiply(d) || dist_sync(d) || dist_download(d, d->d_y, y);
+    int rc = dist_upload_x(d, x) || dist_run(d, kOpProductSync) || dist_download(d, d->d_y, y);
     (void)hipSetDevice(prev);
     return rc;
 }
@@ -691,7 +1096,7 @@ int spmv_hip_dist_bench(spmv_hip_dist *d, int min_iters, double min_seconds, dou
     int rc = 1, it = 0;
     double total = 0.0;
     do {
-        if (dist_upload_x(d, x) || dist_sync(d)) break;
+        if (dist_upload_x(d, x) || dist_run(d, kOpSync)) break;
         const auto t0 = std::chrono::steady_clock::now();
         bool failed = false;
         for (;;) {
@@ -699,30 +1104,11 @@ int spmv_hip_dist_bench(spmv_hip_dist *d, int min_iters, double min_seconds, dou
             // timed: the exchange and the products of all blocks, from the first launch to the last
             // block's completion (driver_spmv.c:297-300 times the one mult call the same way)
             const auto t1 = std::chrono::steady_clock::now();
-            if (dist_exchange_and_multiply(d) || dist_sync(d)) { failed = true; break; }
+            if (dist_run(d, kOpProductSync)) { failed = true; break; }
             const auto t2 = std::chrono::steady_clock::now();
             total += std::chrono::duration<double>(t2 - t1).count();
             // untimed: x = y / ||y||_2 with the norm over all blocks (driver_spmv.c:301-302)
-            double sumsq = 0.0;
-            for (int p = 0; p < d->ngpus && !failed; p++) {
-                if (hipSetDevice(d->device[p]) != hipSuccess ||
-                    launch_norm2(d->block[p]->rows, d->d_y[p], d->dtype, d->d_norm[p], d->compute[p])) { failed = true; break; }
-            }
-            for (int p = 0; p < d->ngpus && !failed; p++) {
-                double part = 0.0;
-                if (hipSetDevice(d->device[p]) != hipSuccess ||
-                    hipMemcpyAsync(&part, d->d_norm[p], sizeof part, hipMemcpyDeviceToHost, d->compute[p]) != hipSuccess ||
-                    hipStreamSynchronize(d->compute[p]) != hipSuccess) { failed = true; break; }
-                sumsq += part * part;
-            }
-            const double norm = std::sqrt(sumsq);
-            for (int p = 0; p < d->ngpus && !failed; p++) {
-                if (hipSetDevice(d->device[p]) != hipSuccess ||
-                    hipMemcpyAsync(d->d_norm[p], &norm, sizeof norm, hipMemcpyHostToDevice, d->compute[p]) != hipSuccess ||
-                    launch_scale(d->block[p]->rows, d->d_y[p], d->d_x[p], d->dtype, d->d_norm[p], d->compute[p]) ||
-                    hipStreamSynchronize(d->compute[p]) != hipSuccess) { failed = true; break; }
-            }
-            if (failed) break;
+            if (dist_run(d, kOpNormScale)) { failed = true; break; }
             const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (wall > min_seconds && it >= min_iters) break;
         }
@@ -736,12 +1122,46 @@ int spmv_hip_dist_bench(spmv_hip_dist *d, int min_iters, double min_seconds, dou
     return rc;
 }
 
+int spmv_hip_dist_issue_time(spmv_hip_dist *d, int products, double *issue_seconds, double *total_seconds)
+{
+    clear_error();
+    if (!d || products < 1 || !issue_seconds || !total_seconds) { set_error("dist_issue_time: bad argument"); return 1; }
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    double issue = 0.0, total = 0.0;
+    int rc = dist_run(d, kOpSync);
+    for (int k = 0; k < products && !rc; k++) {
+        const auto t1 = std::chrono::steady_clock::now();
+        rc = dist_run(d, kOpProduct);                    // returns once every block's launches are issued
+        const auto t2 = std::chrono::steady_clock::now();
+        rc = rc || dist_run(d, kOpSync);
+        const auto t3 = std::chrono::steady_clock::now();
+        issue += std::chrono::duration<double>(t2 - t1).count();
+        total += std::chrono::duration<double>(t3 - t1).count();
+    }
+    (void)hipSetDevice(prev);
+    *issue_seconds = issue;
+    *total_seconds = total;
+    return rc;
+}
+
 int spmv_hip_dist_set_option(spmv_hip_dist *d, const char *name, int64_t value)
 {
     if (!d) { set_error("NULL handle"); return 1; }
     for (int p = 0; p < d->ngpus; p++)
         if (spmv_hip_rowblock_set_option(d->block[(size_t)p], name, value)) return 1;
     return 0;
+}
+
+int spmv_hip_dist_analyze(spmv_hip_dist *d, int reps)
+{
+    clear_error();
+    if (!d) { set_error("NULL handle"); return 1; }
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    const int rc = dist_run(d, kOpAnalyze, reps);
+    (void)hipSetDevice(prev);
+    return rc;
 }
 
 int spmv_hip_dist_get_info(const spmv_hip_dist *d, int *ngpus, int *bounds, spmv_hip_rowblock_info *blocks)
@@ -753,6 +1173,13 @@ int spmv_hip_dist_get_info(const spmv_hip_dist *d, int *ngpus, int *bounds, spmv
     if (blocks)
         for (int p = 0; p < d->ngpus; p++)
             if (spmv_hip_rowblock_get_info(d->block[(size_t)p], &blocks[p])) return 1;
+    return 0;
+}
+
+int spmv_hip_dist_get_peer_access(const spmv_hip_dist *d, int *access)
+{
+    if (!d || !access) { set_error("NULL argument"); return 1; }
+    for (size_t k = 0; k < d->peer.size(); k++) access[k] = d->peer[k];
     return 0;
 }
 

@@ -36,10 +36,13 @@ from . import _lib as L
 
 
 class HipEngine:
-    """Local products on libspmv_hip with tensors resident in HBM."""
+    """Local products on libspmv_hip with tensors resident in HBM.  `exact_order`: the kernel trials may
+    only pick variants that leave y's bits as the default kernels give them (set before the first trial,
+    so the bits do not depend on what a trial measures)."""
 
-    def __init__(self, dtype):
+    def __init__(self, dtype, exact_order=False):
         self.dtype = dtype
+        self.exact_order = exact_order
         self.tdtype = torch.float64 if dtype == L.F64 else torch.float32
 
     def _arrays(self, rp, cj, va):
@@ -56,6 +59,8 @@ class HipEngine:
         st = torch.cuda.current_stream().cuda_stream
         m = Matrix.from_device_csr(fmt, rows, cols, nnz, rp.data_ptr(), cj.data_ptr(), va.data_ptr(), self.dtype,
                                    p0, p1, st, keepalive=(rp, cj, va))
+        if self.exact_order:
+            m.set_option("exact_order", 1)
         m.analyze(3)
         return _HipLocal(m)
 
@@ -65,7 +70,11 @@ class HipEngine:
         st = torch.cuda.current_stream().cuda_stream
         h = L.check_handle(L.lib().spmv_hip_rowblock_create(fmt, rows, row_begin, cols_global, nnz, rp.data_ptr(),
                                                             cj.data_ptr(), va.data_ptr(), self.dtype, p0, p1, st))
-        return _HipRowBlock(h)          # the library has copied what it keeps: rp, cj, va may go
+        blk = _HipRowBlock(h)           # the library has copied what it keeps: rp, cj, va may go
+        if self.exact_order:
+            L.check(L.lib().spmv_hip_rowblock_set_option(h, b"exact_order", 1))
+        blk.analyze(3)                  # a new block runs its default kernels until a trial has picked others
+        return blk
 
 
 class _HipLocal:
@@ -93,7 +102,12 @@ class _HipRowBlock:
         self.halo_columns = torch.from_numpy(halo[:info.halo].astype(np.int64))
 
     def set_option(self, name, value):
+        """Sets the option and repeats the kernel trial under it."""
         L.check(L.lib().spmv_hip_rowblock_set_option(self._h, name.encode(), value))
+        self.analyze(3)
+
+    def analyze(self, reps=3):
+        L.check(L.lib().spmv_hip_rowblock_analyze(self._h, reps))
         info = L.RowBlockInfo()
         L.check(L.lib().spmv_hip_rowblock_get_info(self._h, C.byref(info)))
         self.info, self.variant = info, info.interior_variant

@@ -1,4 +1,4 @@
-"""Row-block multi-process SpMV on CPU: gloo, world_size 2 and 3.
+"""Row-block multi-process SpMV on CPU: gloo, world_size 2, 3 and 8.
 
 The partitioning, halo bookkeeping and exchange of spmv_amd.distributed are the
 code under test; the local products are done by the CPU oracle through an
@@ -95,6 +95,11 @@ def _worker(rank, world, port, exchange, kind, out_q):
             per = (nz // world) * nx * ny
             r0, r1 = rank * per, (rank + 1) * per
             rows, cols, rp, cj, va = G.stencil27(nx, ny, nz, row_begin=r0, row_end=r1)
+        elif kind == "stencil_uneven":          # 53 planes dealt like 530 over 8 GPUs: slabs of 6 or 7 (there: 66 or 67)
+            nx, ny, nz = 5, 4, 53
+            total = nx * ny * nz
+            r0, r1 = (rank * nz // world) * nx * ny, ((rank + 1) * nz // world) * nx * ny
+            rows, cols, rp, cj, va = G.stencil27(nx, ny, nz, row_begin=r0, row_end=r1)
         elif kind == "blockdiag":               # no rank needs anything from another one
             per = 50
             total = per * world
@@ -151,9 +156,14 @@ def test_row_blocks_by_nnz_balances_and_snaps():
     assert row_blocks_by_nnz(rp, 2, snap=64) == [0, 1024, 2048]
 
 
-@pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("exchange,kind", [("halo", "stencil"), ("allgather", "stencil"), ("halo", "powerlaw"),
-                                           ("allgather", "powerlaw"), ("halo", "powerlaw_nnz"), ("halo", "blockdiag")])
+CASES = [(w, e, k) for w in (2, 3) for e, k in (("halo", "stencil"), ("allgather", "stencil"), ("halo", "powerlaw"),
+                                                   ("allgather", "powerlaw"), ("halo", "powerlaw_nnz"), ("halo", "blockdiag"))]
+# the node's own shape: 8 ranks -- uneven slabs (ranks with one and with two neighbours), equal slabs through
+# the all-gather, equal nnz shares of skewed rows
+CASES += [(8, "halo", "stencil_uneven"), (8, "allgather", "stencil"), (8, "halo", "powerlaw_nnz")]
+
+
+@pytest.mark.parametrize("world,exchange,kind", CASES)
 def test_row_block_spmv_matches_single_process(orc, world, exchange, kind):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -167,6 +177,8 @@ def test_row_block_spmv_matches_single_process(orc, world, exchange, kind):
         assert p.exitcode == 0
     if kind == "stencil":
         rows, cols, rp, cj, va = G.stencil27(7, 6, 4 * world)
+    elif kind == "stencil_uneven":
+        rows, cols, rp, cj, va = G.stencil27(5, 4, 53)
     elif kind == "blockdiag":
         blocks = [G.band(50, 3, seed=r + 1) for r in range(world)]
         rows = cols = 50 * world
@@ -187,8 +199,37 @@ def test_row_block_spmv_matches_single_process(orc, world, exchange, kind):
         got[r0:r0 + len(y)] = y
         got2[r0:r0 + len(y2)] = y2
         assert abs(nrm - np.linalg.norm(want)) <= 1e-12 * np.linalg.norm(want)
-        if exchange == "halo" and kind == "stencil":
+        if exchange == "halo" and kind in ("stencil", "stencil_uneven"):
             planes = 2 if 0 < rank < world - 1 else 1
-            assert nhalo == planes * 7 * 6                 # only the neighbouring planes travel
+            assert nhalo == planes * (7 * 6 if kind == "stencil" else 5 * 4)     # only the neighbouring planes travel
     assert got.tobytes() == want.tobytes()
     assert got2.tobytes() == want2.tobytes()
+
+
+def test_partition_of_the_530_cube_into_8_blocks():
+    """BASELINE config 4's matrix (27-point stencil 530^3: 148 877 000 rows, 1588^3 = 4 004 529 472 non-zeros, more
+    than an int counts) never exists in one piece; its row pointers follow from the grid: a row has
+    3 - [on a face] entries per dimension.  spmv_hip_partition_rows64 and row_blocks_by_nnz must cut them alike:
+    equal shares of the non-zeros (reference rule: csr_bal.c:83-85), boundaries on multiples of 1024 rows."""
+    import ctypes as C
+    import spmv_amd as S
+    from spmv_amd.distributed import row_blocks_by_nnz
+    n = 530
+    per_dim = np.full(n, 3, np.int64)
+    per_dim[0] = per_dim[-1] = 2
+    lens = (per_dim[:, None, None] * per_dim[None, :, None] * per_dim[None, None, :]).reshape(-1)     # z slowest
+    rp = np.zeros(n ** 3 + 1, np.int64)
+    np.cumsum(lens, out=rp[1:])
+    del lens
+    assert rp[-1] == (3 * n - 2) ** 3 == 4_004_529_472
+    bounds = np.zeros(9, np.int32)
+    assert S.lib().spmv_hip_partition_rows64(n ** 3, rp.ctypes.data_as(C.c_void_p), 8, 1024, bounds.ctypes.data_as(C.c_void_p)) == 0
+    assert bounds.tolist() == row_blocks_by_nnz(torch.from_numpy(rp), 8, 1024)
+    assert bounds[0] == 0 and bounds[-1] == n ** 3 and all(b % 1024 == 0 for b in bounds[1:-1])
+    shares = np.diff(rp[bounds.astype(np.int64)])
+    assert shares.max() < 2 ** 31 - 4096                                    # every block fits the 32-bit positions of one GPU
+    assert np.abs(shares - rp[-1] / 8).max() <= 1024 * 27                   # off by at most one snap of full rows
+    # each cut lies within half a plane of the plane boundary an even split by planes (66 or 67 each) would use,
+    # a little outward of it for the first and last blocks, whose outer faces hold shorter rows
+    plane = n * n
+    assert all(abs(int(b) - plane * (530 * k // 8)) < plane for k, b in enumerate(bounds))

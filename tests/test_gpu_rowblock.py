@@ -1,6 +1,6 @@
 """The row-block partitioned product behind the C ABI (spmv_hip_partition_rows, spmv_hip_rowblock_*,
-spmv_hip_dist_*): the split built in HBM against a numpy restatement, and whole products of 1, 2, 3
-and 5 blocks -- all on this box's one GPU, which runs the same pack / peer copy / interior / boundary
+spmv_hip_dist_*): the split built in HBM against a numpy restatement, and whole products of 1, 2, 3,
+5 and 8 blocks -- all on this box's one GPU, which runs the same pack / peer copy / interior / boundary
 sequence as distinct devices do -- against the oracle's single-process mult_csr_base.
 
 The reference has no partitioned product (its precedent: the equal-nnz chunks of create_csr_bal,
@@ -98,7 +98,7 @@ def _dist(fmt, rows, cols, coo, dtype, p0, p1, ngpus):
                                                        p1, ngpus, dev))
 
 
-@pytest.mark.parametrize("ngpus", [1, 2, 3, 5])
+@pytest.mark.parametrize("ngpus", [1, 2, 3, 5, 8])
 @pytest.mark.parametrize("name", ["stencil", "powerlaw", "rmat"])
 def test_dist_product_of_n_blocks_matches_the_oracle(orc, name, ngpus):
     rows, cols, rp, cj, va = _matrices()[name]
@@ -118,8 +118,13 @@ def test_dist_product_of_n_blocks_matches_the_oracle(orc, name, ngpus):
         assert n.value == ngpus and bounds[0] == 0 and bounds[-1] == rows
         assert bounds.tolist() == row_blocks_by_nnz(rp, ngpus, 1024)
         assert sum(b.nnz for b in blocks) == len(coo) and all(b.rows == bounds[k + 1] - bounds[k] for k, b in enumerate(blocks))
+        access = np.full(ngpus * ngpus, -1, np.int32)
+        assert lib.spmv_hip_dist_get_peer_access(d, access.ctypes.data_as(C.c_void_p)) == 0
+        assert (access == 2).all()                      # every block sits on device 0
         xin = x.astype(np.float32).astype(np.float64) if dtype == S.F32 else x
         for scale in (1.0, -2.5):                       # twice: the exchange buffers and streams are reused
+            if scale != 1.0:                            # first on the default kernels, then on what the trial picks
+                L.check(lib.spmv_hip_dist_analyze(d, 2))
             y = np.full(rows, np.nan)
             xs = np.ascontiguousarray(xin * scale)
             L.check(lib.spmv_hip_dist_mult(d, xs.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p)))
@@ -164,3 +169,88 @@ def test_dist_rejects_bad_arguments():
     assert not lib.spmv_hip_dist_create(S.SELL, rows, cols, len(coo), coo.ctypes.data_as(C.c_void_p), S.F64, 64, 1024, 1, far)
     assert b"does not exist" in lib.spmv_hip_last_error()
     assert not lib.spmv_hip_dist_create(S.SELL, rows, cols, len(coo), coo.ctypes.data_as(C.c_void_p), S.F64, 64, 1024, 0, None)
+
+
+def _device_blocks(fmt, rows, cols, rp, cj, va, dtype, p0, p1, bounds):
+    """One spmv_hip_rowblock per row range of `bounds`, each from its CSR shard in HBM (global columns)."""
+    td = torch.float64 if dtype == S.F64 else torch.float32
+    out = []
+    for r0, r1 in zip(bounds, bounds[1:]):
+        rp_b, cj_b, va_b = slice_row_block(rp, cj, va, r0, r1)
+        rp_d, cj_d, va_d = rp_b.to(DEV), cj_b.to(DEV), va_b.to(td).to(DEV)
+        if cj_d.numel() == 0:
+            cj_d, va_d = torch.zeros(1, dtype=torch.int32, device=DEV), torch.zeros(1, dtype=td, device=DEV)
+        out.append(L.check_handle(S.lib().spmv_hip_rowblock_create(fmt, r1 - r0, r0, cols, int(rp_b[-1]), rp_d.data_ptr(),
+                                                                    cj_d.data_ptr(), va_d.data_ptr(), dtype, p0, p1, 0)))
+        torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("fmt,p0,p1", [(S.SELL, 64, 1024), (S.CSR_SCALAR, 0, 0)])
+def test_dist_from_blocks_built_shard_by_shard(orc, fmt, p0, p1):
+    """spmv_hip_dist_create_from_blocks: the way a matrix with more non-zeros than an int counts reaches the
+    partitioned product -- no global COO, every block from its own CSR shard in HBM.  8 uneven blocks."""
+    lib = S.lib()
+    rows, cols, rp, cj, va = G.stencil27(12, 11, 53)
+    plane = 12 * 11
+    bounds = [plane * (53 * r // 8) for r in range(9)]                  # slabs of 6 or 7 planes, the 66 / 67 shape of 530 planes
+    blocks = _device_blocks(fmt, rows, cols, rp, cj, va, S.F64, p0, p1, bounds)
+    arr = (C.c_void_p * 8)(*blocks)
+    d = L.check_handle(lib.spmv_hip_dist_create_from_blocks(8, arr))
+    L.check(lib.spmv_hip_dist_set_option(d, b"exact_order", 1))
+    L.check(lib.spmv_hip_dist_analyze(d, 2))
+    got_bounds = np.zeros(9, np.int32)
+    info = (L.RowBlockInfo * 8)()
+    assert lib.spmv_hip_dist_get_info(d, None, got_bounds.ctypes.data_as(C.c_void_p), info) == 0
+    assert got_bounds.tolist() == bounds
+    assert [b.halo for b in info] == [plane] + [2 * plane] * 6 + [plane]     # the neighbouring planes only
+    x = np.random.default_rng(17).random(cols)
+    want = orc.mult_csr_base(rp.numpy(), cj.numpy(), va.numpy(), x)
+    y = np.full(rows, np.nan)
+    L.check(lib.spmv_hip_dist_mult(d, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p)))
+    assert y.tobytes() == want.tobytes()                                # lane-per-row everywhere: mult_csr_base's bits
+    lib.spmv_hip_dist_free(d)                                           # frees the blocks too
+
+
+def test_dist_from_blocks_refuses_blocks_that_do_not_tile_the_matrix():
+    lib = S.lib()
+    rows, cols, rp, cj, va = G.laplacian2d(40)
+    blocks = _device_blocks(S.CSR_SCALAR, rows, cols, rp, cj, va, S.F64, 0, 0, [0, 640, 1600])
+    swapped = (C.c_void_p * 2)(blocks[1], blocks[0])
+    assert not lib.spmv_hip_dist_create_from_blocks(2, swapped)
+    assert b"does not continue" in lib.spmv_hip_last_error()
+    first_only = (C.c_void_p * 1)(blocks[0])
+    assert not lib.spmv_hip_dist_create_from_blocks(1, first_only)
+    assert b"end at row 640 of 1600" in lib.spmv_hip_last_error()
+    for b in blocks:                                                    # after a refusal the blocks are still the caller's
+        assert lib.spmv_hip_rowblock_free(b) == 0
+
+
+@pytest.mark.parametrize("threads,direct", [("1", "1"), ("0", "1"), ("1", "0")])
+@pytest.mark.parametrize("fmt,p0", [(S.CSR_MERGE, 0), (S.CSR_VECTOR, 0), (S.SELL, 64)])
+def test_exact_order_pins_the_bits_of_a_partitioned_product(orc, fmt, p0, threads, direct, monkeypatch):
+    """"exact_order" set before the first kernel trial: whatever the trials measure, y has the bits of the
+    handles' default kernels -- over repeated create / analyze cycles, with the launches issued by the helper
+    threads (default) and by the calling thread (SPMV_DIST_THREADS=0), the halo stored straight into the
+    consumers' vectors (default) and packed, then copied (SPMV_DIST_DIRECT_PUSH=0)."""
+    monkeypatch.setenv("SPMV_DIST_THREADS", threads)
+    monkeypatch.setenv("SPMV_DIST_DIRECT_PUSH", direct)
+    lib = S.lib()
+    rows, cols, rp, cj, va = G.power_law_rows(6000, seed=11)
+    coo_sorted = G.csr_to_coo_numpy(rows, rp, cj, va)
+    x = np.random.default_rng(2).random(cols)
+    want = orc.mult_csr_base(rp.numpy(), cj.numpy(), va.numpy(), x)
+    seen = set()
+    for cycle in range(3):
+        d = _dist(fmt, rows, cols, coo_sorted.copy(), S.F64, p0, 1024 if fmt == S.SELL else 0, 3)
+        y0 = np.full(rows, np.nan)
+        L.check(lib.spmv_hip_dist_mult(d, x.ctypes.data_as(C.c_void_p), y0.ctypes.data_as(C.c_void_p)))   # default kernels
+        L.check(lib.spmv_hip_dist_set_option(d, b"exact_order", 1))
+        L.check(lib.spmv_hip_dist_analyze(d, 1 + cycle))
+        y = np.full(rows, np.nan)
+        L.check(lib.spmv_hip_dist_mult(d, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p)))
+        assert y.tobytes() == y0.tobytes()
+        assert orc.rel_l2(y, want) <= 1e-13
+        seen.add(y.tobytes())
+        lib.spmv_hip_dist_free(d)
+    assert len(seen) == 1

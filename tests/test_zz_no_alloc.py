@@ -24,7 +24,7 @@ def _both(n, v, dtype):
 
 
 @pytest.mark.parametrize("dtype,td", [(S.F64, torch.float64), (S.F32, torch.float32)])
-def test_noalloc_norm_equals_the_allocating_one_on_two_calls_in_a_row(dtype, td):
+def test_noalloc_norm_equals_the_allocating_one_on_two_calls_in_a_row(orc, dtype, td):
     assert S.lib().spmv_hip_init(0) == 0
     g = torch.Generator(device=DEV).manual_seed(21)
     big = torch.rand(5_000_011, dtype=td, device=DEV, generator=g) - 0.5          # all 1024 partial sums in use
@@ -35,6 +35,10 @@ def test_noalloc_norm_equals_the_allocating_one_on_two_calls_in_a_row(dtype, td)
         assert a.tobytes() == b.tobytes()
         want = float(torch.linalg.vector_norm(v.to(torch.float64)))
         assert abs(b - want) <= 1e-12 * want
+        # the driver's vec_norm (driver_spmv.c:21-26) as the oracle restates it: a sequential sum, so by tolerance
+        host = np.ascontiguousarray(v.to(torch.float64).cpu().numpy())
+        ref = orc.lib().orc_vec_norm(len(host), host)
+        assert abs(b - ref) <= 1e-12 * ref
     a, b = _both(0, tiny, dtype)                                                   # empty input: norm 0
     assert a == 0.0 and b == 0.0
 

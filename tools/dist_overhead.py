@@ -5,6 +5,9 @@ on the same device, interior and boundary products on a stream pair per block). 
 blocks run side by side; here they share the GPU, so the ideal is the plain product's time.
 
     python tools/dist_overhead.py --n 160 --format sell --blocks 1,2,4,8
+
+Every block count runs twice: launches issued by the handle's helper threads, one per block (the default), and
+by the calling thread alone (SPMV_DIST_THREADS=0).
 """
 import argparse
 import ctypes as C
@@ -37,14 +40,21 @@ def main():
     it, sec = C.c_int(0), C.c_double(0.0)
     print(f"stencil27 {args.n}^3: {rows} rows, {nnz} nnz, {args.format}")
     for nb in [int(v) for v in args.blocks.split(",")]:
-        devices = (C.c_int * nb)(*([0] * nb))
-        d = L.check_handle(lib.spmv_hip_dist_create(fmt, rows, cols, nnz, coo.ctypes.data_as(C.c_void_p), S.F64, p0, p1, nb, devices))
-        x = np.full(rows, 1.0 / np.sqrt(rows))
-        L.check(lib.spmv_hip_dist_bench(d, 10, args.seconds, x.ctypes.data_as(C.c_void_p), C.byref(it), C.byref(sec)))
-        ms = sec.value / it.value * 1e3
-        print(f"  {nb} block(s) on device 0: {ms:.4f} ms per product (host clock, {it.value} products), "
-              f"{2.0 * nnz / ms / 1e6:.0f} GFLOP/s", flush=True)
-        lib.spmv_hip_dist_free(d)
+        for threads in ("1", "0"):
+            os.environ["SPMV_DIST_THREADS"] = threads          # read when the handle is created
+            devices = (C.c_int * nb)(*([0] * nb))
+            d = L.check_handle(lib.spmv_hip_dist_create(fmt, rows, cols, nnz, coo.ctypes.data_as(C.c_void_p), S.F64, p0, p1, nb, devices))
+            L.check(lib.spmv_hip_dist_analyze(d, 3))
+            x = np.full(rows, 1.0 / np.sqrt(rows))
+            L.check(lib.spmv_hip_dist_bench(d, 10, args.seconds, x.ctypes.data_as(C.c_void_p), C.byref(it), C.byref(sec)))
+            ms = sec.value / it.value * 1e3
+            who = "a helper thread per block" if threads == "1" else "the calling thread alone "
+            issue, total = C.c_double(0.0), C.c_double(0.0)
+            L.check(lib.spmv_hip_dist_issue_time(d, 200, C.byref(issue), C.byref(total)))
+            print(f"  {nb} block(s) on device 0, {who}: {ms:.4f} ms per product (host clock, {it.value} products), "
+                  f"{2.0 * nnz / ms / 1e6:.0f} GFLOP/s; issuing one product takes the host {issue.value / 200 * 1e6:.1f} us",
+                  flush=True)
+            lib.spmv_hip_dist_free(d)
 
 
 if __name__ == "__main__":
