@@ -60,6 +60,7 @@ def lib():
         "orc_mult_mv_csr": (None, [C.c_int, _i32p, _i32p, _f64p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
         "orc_mult_csr_base_f32": (None, [C.c_int, _i32p, _i32p, _f32p, _f32p, _f32p]),
         "orc_mult_csr_omp": (None, [C.c_int, _i32p, _i32p, _f64p, _f64p, _f64p]),
+        "orc_csr_copy_first_touch": (None, [C.c_int, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p, _f64p, _f64p]),
         "orc_merge_path_search": (None, [C.c_int, _i32p, C.c_int, C.c_int,
                                          C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "orc_mult_csr_merge": (None, [C.c_int, C.c_int, _i32p, _i32p, _f64p, _f64p, _f64p,

@@ -167,6 +167,22 @@ void orc_mult_csr_omp(int rows, const int *row_ptr, const int *col, const double
     }
 }
 
+/* csr_numa.c:25-58 pattern: every thread writes (first touches) the rows it will later multiply, so
+ * that their pages land in the memory closest to that thread.  The destination arrays must be fresh
+ * allocations whose pages have not been written yet; row_ptr_dst receives all rows+1 pointers. */
+void orc_csr_copy_first_touch(int rows, const int *row_ptr, const int *col, const double *val,
+                              int *row_ptr_dst, int *col_dst, double *val_dst, double *x_dst, double *y_dst)
+{
+    #pragma omp parallel for schedule(static)
+    for (int k = 0; k < rows; k++) {
+        row_ptr_dst[k] = row_ptr[k];
+        for (int l = row_ptr[k]; l < row_ptr[k + 1]; l++) { col_dst[l] = col[l]; val_dst[l] = val[l]; }
+        x_dst[k] = 0.0;
+        y_dst[k] = 0.0;
+    }
+    row_ptr_dst[rows] = row_ptr[rows];
+}
+
 /* ----------------------------------------------------------- merge path -- */
 
 static inline int imin(int a, int b) { return a < b ? a : b; }

@@ -58,6 +58,10 @@ void orc_mult_csr_base_f32(int rows, const int *row_ptr, const int *col, const f
 /* row-parallel CSR over OpenMP threads (pattern of csr_numa.c:3-23); CPU baseline only */
 void orc_mult_csr_omp(int rows, const int *row_ptr, const int *col, const double *val,
                       const double *x, double *y);
+/* csr_numa.c:25-58: copy of a CSR whose pages are first written by the threads that multiply them
+ * (square matrix: x_dst and y_dst, rows elements each, are touched the same way) */
+void orc_csr_copy_first_touch(int rows, const int *row_ptr, const int *col, const double *val,
+                              int *row_ptr_dst, int *col_dst, double *val_dst, double *x_dst, double *y_dst);
 
 /* csr_merge.c:62-85 */
 void orc_merge_path_search(int diagonal, const int *row_end_offsets, int n, int nz,

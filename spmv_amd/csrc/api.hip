@@ -79,6 +79,9 @@ static spmv_hip_matrix *new_handle(int format, int dtype, int rows, int columns,
     if (!m) { set_error("out of host memory"); return nullptr; }
     m->format = format; m->dtype = dtype; m->rows = rows; m->columns = columns; m->nnz = nnz;
     if (hipGetDevice(&m->device) != hipSuccess) { set_error("no HIP device available"); delete m; return nullptr; }
+    if (hipDeviceGetAttribute(&m->cus, hipDeviceAttributeMultiprocessorCount, m->device) != hipSuccess) m->cus = 0;
+    if (hipDeviceGetAttribute(&m->max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, m->device) != hipSuccess) m->max_lds = 0;
+    (void)hipGetLastError();
     return m;
 }
 

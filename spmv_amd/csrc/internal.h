@@ -55,6 +55,8 @@ struct DeviceGuard {
 // The opaque handle of the C ABI.
 struct spmv_hip_matrix {
     int format = 0, dtype = 0, device = 0;
+    int cus = 0;                   // compute units of the device (read once, when the handle is made)
+    int max_lds = 0;               // bytes of LDS one workgroup may use there
     int rows = 0, columns = 0;
     int64_t nnz = 0;      // true non-zeros
     int64_t stored = 0;   // entries in HBM incl. padding

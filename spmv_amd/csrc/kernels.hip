@@ -1269,7 +1269,8 @@ int variant_candidates(const spmv_hip_matrix *m, int *out, int max_out)
         if (m->d_tile_pat && !m->d_hot_col && m->pat_tiles * 2 >= m->ntiles && n < max_out) out[n++] = 2;
         // persistent workgroups with each column group's hottest labels in LDS (8 or 16 waves), for the
         // stacked matrix of "hot_columns" = 2
-        if (m->group_cpx > 0 && m->items_per_tile == 8 * kWave)
+        // (they use all 160 KiB of a CU's LDS: offered only where one workgroup may have that much)
+        if (m->group_cpx > 0 && m->items_per_tile == 8 * kWave && m->max_lds >= 160 * 1024)
             for (int v : {3, 4})
                 if (n < max_out) out[n++] = v;
     } else if (n < max_out) {
@@ -1475,10 +1476,11 @@ template <typename T> static int launch_tiles(const spmv_hip_matrix *m, const T 
             set_error("tile kernel: variant %d needs the column groups of hot_columns 2 and tiles of 512", m->variant);
             return 1;
         }
-        int cus = 0, dev = 0;
-        SPMV_HIP_TRY(hipGetDevice(&dev), return 1);
-        SPMV_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev), return 1);
-        const dim3 grid((unsigned)std::max(cus / 8, 1) * 8);           // one workgroup per CU, a multiple of the 8 groups
+        if (m->max_lds < 160 * 1024) {
+            set_error("tile kernel: variant %d needs 160 KiB of LDS per workgroup, the device allows %d bytes", m->variant, m->max_lds);
+            return 1;
+        }
+        const dim3 grid((unsigned)std::max(m->cus / 8, 1) * 8);        // one workgroup per CU, a multiple of the 8 groups
         tile_groups tg;
         for (int g = 0; g <= 8; g++) tg.first_tile[g] = m->group_first_tile[g];
         if (m->variant == 3)

@@ -17,7 +17,7 @@ for mode in csr_base csr_vec csr_merge csr_bal ell sellp_vec sell:1024 sell_dfc:
         tag=$(echo "${mode}_$dt" | tr ':' '-')
         rm -rf "$out/tmp"; mkdir -p "$out/tmp"
         LIST=matrix_lists/standins_160.txt MODE="$mode:$dt" OUT="$out/tmp" SPMV_MIN_SECONDS=$secs timeout -k 10 900 ./spmv_hip.run > "$out/$tag.log" 2>&1
-        mv "$out/tmp/0.csv" "$out/$tag.csv"
+        mv "$out/tmp/1.csv" "$out/$tag.csv"
         if [ $first = 1 ]; then head -1 "$out/$tag.csv" > "$out/all.csv"; first=0; fi
         tail -n +2 "$out/$tag.csv" >> "$out/all.csv"
         echo "$tag: $(grep -c ' OK' "$out/$tag.log") OK, $(grep -c ' ERR$' "$out/$tag.log") ERR"
