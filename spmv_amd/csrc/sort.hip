@@ -318,21 +318,103 @@ __global__ void xcd_label_kernel(int cols, int cpx, int snake, const int *__rest
     old_of_label[label] = old;
 }
 
-// cnt[g*rows + r] = entries of row r whose column belongs to group g (thread per row; the eight
-// counters of a thread live in LDS, one bank per thread)
+// Rows of up to kXcdLongRow entries are walked by one lane each; a longer row (a power-law matrix has rows of
+// several hundred thousand entries, and one lane walking such a row alone takes longer than the rest of
+// the build together) is walked by the whole wave, 64 entries per step with coalesced loads.
+constexpr int kXcdLongRow = 96;
+
+__device__ __forceinline__ int xcd_group_of(int label, int cpx)
+{
+    int g = 0;
+#pragma unroll
+    for (int k = 1; k < kXcds; k++) g += label >= k * cpx;
+    return g;
+}
+
+// A row beyond kXcdHugeRow entries is cut into segments of kXcdSegment entries, each walked by a wave of its own
+// (xcd_count_huge_kernel, xcd_fill_huge_kernel): the first 64 rows of an R-MAT matrix hold millions of entries
+// between them, and a single wave walking them one after the other would be the whole build's critical path.
+constexpr int kXcdHugeRow = 8192, kXcdSegment = 4096;
+
+// cnt[g*rows + r] = entries of row r whose column belongs to group g; huge rows are only listed here
+// (huge_rows[0 .. meta[0]), longest of them in meta[1]) and counted by xcd_count_huge_kernel
 __global__ __launch_bounds__(256) void xcd_count_kernel(int rows, int cpx, const int *__restrict__ row_ptr,
                                                         const int *__restrict__ col,
-                                                        const int *__restrict__ label_of_old, int *__restrict__ cnt)
+                                                        const int *__restrict__ label_of_old, int *__restrict__ cnt,
+                                                        int *__restrict__ huge_rows, int *__restrict__ meta)
 {
-    __shared__ int c[kXcds][256];
+    __shared__ int c[kXcds][256];              // the eight counters of a lane, one bank per lane
     const int r = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     for (int g = 0; g < kXcds; g++) c[g][threadIdx.x] = 0;
-    if (r < rows)
-        for (int e = row_ptr[r]; e < row_ptr[r + 1]; e++) c[label_of_old[col[e]] / cpx][threadIdx.x]++;
-    if (r < rows)
+    const int rs = r < rows ? row_ptr[r] : 0, re = r < rows ? row_ptr[r + 1] : 0;
+    const bool is_huge = re - rs > kXcdHugeRow;
+    const bool is_long = re - rs > kXcdLongRow && !is_huge;
+    if (is_huge) {
+        huge_rows[atomicAdd(&meta[0], 1)] = r;
+        atomicMax(&meta[1], re - rs);
+    }
+    if (!is_long && !is_huge)
+        for (int e = rs; e < re; e++) c[xcd_group_of(label_of_old[col[e]], cpx)][threadIdx.x]++;
+    unsigned long long longs = __ballot(is_long);
+    while (longs) {
+        const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(longs));
+        longs &= longs - 1;
+        const int ls = __builtin_amdgcn_readlane(rs, src), le = __builtin_amdgcn_readlane(re, src);
+        int mine[kXcds] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int e = ls + lane; e < le; e += 64) {
+            const int g = xcd_group_of(label_of_old[col[e]], cpx);
+#pragma unroll
+            for (int k = 0; k < kXcds; k++) mine[k] += g == k;
+        }
+#pragma unroll
+        for (int k = 0; k < kXcds; k++) {
+            int t = mine[k];
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+            if (lane == src) c[k][threadIdx.x] = t;
+        }
+    }
+    if (r < rows && !is_huge)
         for (int g = 0; g < kXcds; g++) cnt[(size_t)g * rows + r] = c[g][threadIdx.x];
 }
 
+__global__ void xcd_zero_rows_kernel(int rows, int n, const int *__restrict__ which, int *__restrict__ cnt)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    for (int g = 0; g < kXcds; g++) cnt[(size_t)g * rows + which[k]] = 0;
+}
+
+// One wave per (huge row, segment), blockIdx.x = row index * nseg + segment: seg_cnt[blockIdx.x * 8 + g] = entries of
+// the segment in group g, also added to the row's total in cnt (zeroed by the caller for these rows).
+__global__ __launch_bounds__(64) void xcd_count_huge_kernel(int rows, int cpx, int nseg, const int *__restrict__ row_ptr,
+                                                            const int *__restrict__ col,
+                                                            const int *__restrict__ label_of_old,
+                                                            const int *__restrict__ huge_rows, int *__restrict__ seg_cnt,
+                                                            int *__restrict__ cnt)
+{
+    const int which = (int)(blockIdx.x / (unsigned)nseg), seg = (int)(blockIdx.x % (unsigned)nseg);
+    const int r = huge_rows[which], lane = threadIdx.x;
+    const int rs = row_ptr[r], re = row_ptr[r + 1];
+    const int ls = rs + seg * kXcdSegment, le = min(ls + kXcdSegment, re);
+    int mine[kXcds] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int e = ls + lane; e < le; e += 64) {
+        const int g = xcd_group_of(label_of_old[col[e]], cpx);
+#pragma unroll
+        for (int k = 0; k < kXcds; k++) mine[k] += g == k;
+    }
+#pragma unroll
+    for (int k = 0; k < kXcds; k++) {
+        int t = mine[k];
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+        if (lane == 0) {
+            seg_cnt[((size_t)which * nseg + seg) * kXcds + k] = t;
+            if (t) atomicAdd(&cnt[(size_t)k * rows + r], t);
+        }
+    }
+}
+
+// The entries of every row dealt to the row's eight virtual rows, in their order inside the row.
 template <typename TIN, typename T>
 __global__ __launch_bounds__(256) void xcd_fill_kernel(int rows, int cpx, const int *__restrict__ row_ptr,
                                                        const int *__restrict__ col, const TIN *__restrict__ val,
@@ -342,13 +424,89 @@ __global__ __launch_bounds__(256) void xcd_fill_kernel(int rows, int cpx, const 
 {
     __shared__ int cursor[kXcds][256];
     const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= rows) return;
-    for (int g = 0; g < kXcds; g++) cursor[g][threadIdx.x] = vrow_ptr[(size_t)g * rows + r];
-    for (int e = row_ptr[r]; e < row_ptr[r + 1]; e++) {
-        const int label = label_of_old[col[e]];
-        const int at = cursor[label / cpx][threadIdx.x]++;
-        vcol[at] = label;
-        vval[at] = (T)val[e];
+    const int lane = threadIdx.x & 63;
+    const int rs = r < rows ? row_ptr[r] : 0, re = r < rows ? row_ptr[r + 1] : 0;
+    const bool is_huge = re - rs > kXcdHugeRow;                 // filled by xcd_fill_huge_kernel
+    const bool is_long = re - rs > kXcdLongRow && !is_huge;
+    if (r < rows && !is_long && !is_huge) {
+        for (int g = 0; g < kXcds; g++) cursor[g][threadIdx.x] = vrow_ptr[(size_t)g * rows + r];
+        for (int e = rs; e < re; e++) {
+            const int label = label_of_old[col[e]];
+            const int at = cursor[xcd_group_of(label, cpx)][threadIdx.x]++;
+            vcol[at] = label;
+            vval[at] = (T)val[e];
+        }
+    }
+    unsigned long long longs = __ballot(is_long);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    while (longs) {
+        const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(longs));
+        longs &= longs - 1;
+        const int ls = __builtin_amdgcn_readlane(rs, src), le = __builtin_amdgcn_readlane(re, src);
+        const int row = __builtin_amdgcn_readlane(r, src);
+        int next[kXcds];                            // where each group's next entry of this row goes (wave-uniform)
+#pragma unroll
+        for (int k = 0; k < kXcds; k++) next[k] = vrow_ptr[(size_t)k * rows + row];
+        for (int base = ls; base < le; base += 64) {
+            const int e = base + lane;
+            const bool live = e < le;
+            const int label = live ? label_of_old[col[e]] : 0;
+            const int g = xcd_group_of(label, cpx);
+            int at = 0;
+#pragma unroll
+            for (int k = 0; k < kXcds; k++) {       // entry order inside the row is kept: lanes of one group rank by lane
+                const unsigned long long mask = __ballot(live && g == k);
+                if (g == k) at = next[k] + __popcll(mask & below);
+                next[k] += __popcll(mask);
+            }
+            if (live) {
+                vcol[at] = label;
+                vval[at] = (T)val[e];
+            }
+        }
+    }
+}
+
+// One wave per (huge row, segment): the segment's entries go behind those of the row's earlier segments.
+template <typename TIN, typename T>
+__global__ __launch_bounds__(64) void xcd_fill_huge_kernel(int rows, int cpx, int nseg, const int *__restrict__ row_ptr,
+                                                           const int *__restrict__ col, const TIN *__restrict__ val,
+                                                           const int *__restrict__ label_of_old,
+                                                           const int *__restrict__ huge_rows,
+                                                           const int *__restrict__ seg_cnt,
+                                                           const int *__restrict__ vrow_ptr, int *__restrict__ vcol,
+                                                           T *__restrict__ vval)
+{
+    const int which = (int)(blockIdx.x / (unsigned)nseg), seg = (int)(blockIdx.x % (unsigned)nseg);
+    const int r = huge_rows[which], lane = threadIdx.x;
+    const int rs = row_ptr[r], re = row_ptr[r + 1];
+    const int ls = rs + seg * kXcdSegment, le = min(ls + kXcdSegment, re);
+    if (ls >= le) return;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int next[kXcds];
+#pragma unroll
+    for (int k = 0; k < kXcds; k++) {
+        int before = 0;                             // entries of group k in the row's earlier segments
+        for (int sgm = lane; sgm < seg; sgm += 64) before += seg_cnt[((size_t)which * nseg + sgm) * kXcds + k];
+        for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
+        next[k] = vrow_ptr[(size_t)k * rows + r] + before;
+    }
+    for (int base = ls; base < le; base += 64) {
+        const int e = base + lane;
+        const bool live = e < le;
+        const int label = live ? label_of_old[col[e]] : 0;
+        const int g = xcd_group_of(label, cpx);
+        int at = 0;
+#pragma unroll
+        for (int k = 0; k < kXcds; k++) {
+            const unsigned long long mask = __ballot(live && g == k);
+            if (g == k) at = next[k] + __popcll(mask & below);
+            next[k] += __popcll(mask);
+        }
+        if (live) {
+            vcol[at] = label;
+            vval[at] = (T)val[e];
+        }
     }
 }
 
@@ -368,6 +526,7 @@ int build_xcd_columns(const spmv_hip_matrix *m, bool val_is_f64, hipStream_t st,
     const int snake = std::min(65536, cols / (16 * kXcds) * (16 * kXcds));
     unsigned *d_count[2] = {nullptr, nullptr};
     int *d_id = nullptr, *d_rank_old = nullptr, *d_label_of_old = nullptr, *d_cnt = nullptr;
+    int *d_huge = nullptr, *d_meta = nullptr, *d_seg_cnt = nullptr;
     void *d_temp = nullptr;
     int *vrp = nullptr, *vcol = nullptr, *old_of_label = nullptr;
     void *vval = nullptr;
@@ -380,6 +539,8 @@ int build_xcd_columns(const spmv_hip_matrix *m, bool val_is_f64, hipStream_t st,
         SPMV_HIP_TRY(hipMalloc((void **)&d_label_of_old, c * sizeof(int)), break);
         SPMV_HIP_TRY(hipMalloc((void **)&old_of_label, labels * sizeof(int)), break);
         SPMV_HIP_TRY(hipMalloc((void **)&d_cnt, (vrows + 1) * sizeof(int)), break);
+        SPMV_HIP_TRY(hipMalloc((void **)&d_huge, ((size_t)(n / kXcdHugeRow) + 1) * sizeof(int)), break);
+        SPMV_HIP_TRY(hipMalloc((void **)&d_meta, 2 * sizeof(int)), break);
         SPMV_HIP_TRY(hipMalloc((void **)&vrp, (vrows + 1) * sizeof(int)), break);
         SPMV_HIP_TRY(hipMalloc((void **)&vcol, (size_t)n * sizeof(int)), break);
         SPMV_HIP_TRY(hipMalloc(&vval, (size_t)n * dtype_size(m->dtype)), break);
@@ -415,9 +576,27 @@ int build_xcd_columns(const spmv_hip_matrix *m, bool val_is_f64, hipStream_t st,
             *out_used_cpx = (int)std::min<size_t>(snake / kXcds + ((referenced - snake + 16 * kXcds - 1) / (16 * kXcds)) * 16, (size_t)cpx);
         SPMV_HIP_TRY(hipMemsetAsync(old_of_label, 0xFF, labels * sizeof(int), st), break);
         hipLaunchKernelGGL(xcd_label_kernel, gcol, block, 0, st, cols, cpx, snake, d_rank_old, d_label_of_old, old_of_label);
-        hipLaunchKernelGGL(xcd_count_kernel, grow, block, 0, st, rows, cpx, m->d_row_ptr, m->d_col, d_label_of_old, d_cnt);
+        SPMV_HIP_TRY(hipMemsetAsync(d_meta, 0, 2 * sizeof(int), st), break);
+        hipLaunchKernelGGL(xcd_count_kernel, grow, block, 0, st, rows, cpx, m->d_row_ptr, m->d_col, d_label_of_old, d_cnt,
+                           d_huge, d_meta);
         SPMV_HIP_TRY(hipMemsetAsync(d_cnt + vrows, 0, sizeof(int), st), break);
         SPMV_HIP_TRY(hipGetLastError(), break);
+        // the huge rows, a wave per segment
+        int meta[2] = {0, 0};
+        SPMV_HIP_TRY(hipMemcpyAsync(meta, d_meta, sizeof meta, hipMemcpyDeviceToHost, st), break);
+        SPMV_HIP_TRY(hipStreamSynchronize(st), break);
+        const int nhuge = meta[0], nseg = (meta[1] + kXcdSegment - 1) / kXcdSegment;
+        if (nhuge > 0) {
+            if ((int64_t)nhuge * nseg > 0x7fffffffLL / kXcds) {
+                set_error("hot_columns 2: %d rows of more than %d entries, the longest %d", nhuge, kXcdHugeRow, meta[1]);
+                break;
+            }
+            SPMV_HIP_TRY(hipMalloc((void **)&d_seg_cnt, (size_t)nhuge * nseg * kXcds * sizeof(int)), break);
+            hipLaunchKernelGGL(xcd_zero_rows_kernel, dim3((unsigned)((nhuge + 255) / 256)), block, 0, st, rows, nhuge, d_huge, d_cnt);
+            hipLaunchKernelGGL(xcd_count_huge_kernel, dim3((unsigned)(nseg * nhuge)), dim3(64), 0, st, rows, cpx, nseg,
+                               m->d_row_ptr, m->d_col, d_label_of_old, d_huge, d_seg_cnt, d_cnt);
+            SPMV_HIP_TRY(hipGetLastError(), break);
+        }
         if (device_exclusive_scan(d_cnt, vrp, vrows + 1, st)) break;
         if (m->dtype == SPMV_HIP_F32 && val_is_f64)
             hipLaunchKernelGGL((xcd_fill_kernel<double, float>), grow, block, 0, st, rows, cpx, m->d_row_ptr, m->d_col,
@@ -428,13 +607,26 @@ int build_xcd_columns(const spmv_hip_matrix *m, bool val_is_f64, hipStream_t st,
         else
             hipLaunchKernelGGL((xcd_fill_kernel<double, double>), grow, block, 0, st, rows, cpx, m->d_row_ptr, m->d_col,
                                (const double *)m->d_val, d_label_of_old, vrp, vcol, (double *)vval);
+        if (nhuge > 0) {
+            const dim3 gh((unsigned)(nseg * nhuge)), bh(64);
+            if (m->dtype == SPMV_HIP_F32 && val_is_f64)
+                hipLaunchKernelGGL((xcd_fill_huge_kernel<double, float>), gh, bh, 0, st, rows, cpx, nseg, m->d_row_ptr, m->d_col,
+                                   (const double *)m->d_val, d_label_of_old, d_huge, d_seg_cnt, vrp, vcol, (float *)vval);
+            else if (m->dtype == SPMV_HIP_F32)
+                hipLaunchKernelGGL((xcd_fill_huge_kernel<float, float>), gh, bh, 0, st, rows, cpx, nseg, m->d_row_ptr, m->d_col,
+                                   (const float *)m->d_val, d_label_of_old, d_huge, d_seg_cnt, vrp, vcol, (float *)vval);
+            else
+                hipLaunchKernelGGL((xcd_fill_huge_kernel<double, double>), gh, bh, 0, st, rows, cpx, nseg, m->d_row_ptr, m->d_col,
+                                   (const double *)m->d_val, d_label_of_old, d_huge, d_seg_cnt, vrp, vcol, (double *)vval);
+        }
         SPMV_HIP_TRY(hipGetLastError(), break);
         SPMV_HIP_TRY(hipStreamSynchronize(st), break);
         *out_vrp = vrp; *out_vcol = vcol; *out_vval = vval; *out_old_of_label = old_of_label; *out_cpx = cpx;
         vrp = nullptr; vcol = nullptr; vval = nullptr; old_of_label = nullptr;
         rc = 0;
     } while (0);
-    void *scratch[] = {d_count[0], d_count[1], d_id, d_rank_old, d_label_of_old, d_cnt, d_temp, vrp, vcol, vval, old_of_label};
+    void *scratch[] = {d_count[0], d_count[1], d_id, d_rank_old, d_label_of_old, d_cnt, d_huge, d_meta, d_seg_cnt, d_temp, vrp,
+                       vcol, vval, old_of_label};
     for (void *p : scratch)
         if (p) (void)hipFree(p);
     return rc;
