@@ -80,6 +80,7 @@ def main():
                 base += ["--hot", "1"]
             if name.endswith("+xcd"):
                 base += ["--hot", "2"]
+            print(f"  ... {name} {dname}: timing", flush=True)
             try:
                 if args.variants == "general":
                     trial = base + ["--variants", every_index[fmt]]
@@ -93,15 +94,20 @@ def main():
                 fixed = base + ["--variants", str(first["variant"])]
                 if fmt == "csr_vector":
                     fixed += ["--p0", str(first["lanes_per_row"])]
+                if name.endswith("+xcd"):                         # the tile kernel of the column-split copy, as the trial chose it
+                    fixed = base + ["--hot-variants", str(first.get("hot_variant", 0))]
                 moved = {}
                 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
                     d = tempfile.mkdtemp(prefix="ftpmc_", dir="/tmp")
-                    tune(fixed, 5, profiler=["rocprofv3", "--pmc", counter, "-f", "csv", "-d", d, "-o", "p"])
+                    print(f"  ... {name} {dname}: {counter} pass", flush=True)
+                    tune(fixed, 5, profiler=["rocprofv3", "--pmc", counter, "--kernel-include-regex", "spmv::", "-f", "csv", "-d", d, "-o", "p"])
                     moved[counter], kernels = counter_per_product(d, counter, WARMUP + 5)
                     shutil.rmtree(d, ignore_errors=True)
                 bytes_moved = moved["FETCH_SIZE"] * 1024 * 2 + moved["WRITE_SIZE"] * 1024
                 ms, b_alg, nnz = first["median_ms"], first["b_alg"], first["nnz"]
                 variant = f"{first['lanes_per_row']} lanes, {first['variant']}" if fmt == "csr_vector" else str(first["variant"])
+                if name.endswith("+xcd"):
+                    variant += f", tiles {first.get('hot_variant', 0)}"
                 lines.append(f"| {name} | {dname} | {variant} | {ms:.3f} | {2 * nnz / ms / 1e6:.0f} | {b_alg / ms / 1e6:.0f} | "
                              f"{b_alg / ms / 1e6 / 80:.1f} | {bytes_moved / 1e9:.3f} | {bytes_moved / b_alg:.2f} | {bytes_moved / ms / 1e6:.0f} | "
                              f"{bytes_moved / ms / 1e6 / 80:.1f} | {first['stored'] / max(nnz, 1):.3f} |")
