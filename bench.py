@@ -25,8 +25,7 @@ oracle port on the host cores for a bounded sample of the same workload; it runs
 a child process, before this process makes its first GPU call.
 `other_configs` (N = 1, the default command only) carries the other single-GPU
 configurations of the benchmark list, each measured like the headline one: the 2-D
-5-point Laplacian 1000^2 on lane-per-row CSR (the format of csr.c) and on the format
-the trial picks, and the R-MAT scale 26 matrix on balanced CSR as it is and with its
+5-point Laplacian 1000^2 on lane-per-row CSR (the format of csr.c) and on SELLP, and the R-MAT scale 26 matrix on balanced CSR as it is and with its
 columns dealt over the XCDs (option hot_columns 2, with the time of its three kernels).
 For N > 1 the line also carries `rccl` (what the communicator reports) and
 `c_abi_one_process`: the same slabs driven by ONE process through spmv_hip_dist_*
@@ -684,16 +683,14 @@ def main(argv=None):
         if default_run and not args.no_other_configs:
             others = []
             # the 80 MB of this matrix stay in the caches and a product takes ~15 us, so a kernel trial here picks by
-            # noise: both entries name their kernel (the trial's usual picks), and what create_auto chose in this
-            # run is reported beside them
+            # noise: both entries name their kernel (the trial's usual picks).  No kernel trial runs on this matrix, so that
+            # every launch of the headline's kernels in this process belongs to the headline's matrix (the kernel-trace
+            # summary of this command averages per kernel)
             lap = generate("laplacian2d", 1000)
             others.append(other_entry("C1: plain CSR, the format of csr.c (lane per row, the library's default kernel)",
                                       single_gpu_config("laplacian2d", 1000, "csr_scalar", "f64", variant=0, csr=lap)))
             others.append(other_entry("C1: SELLP, kernel that skips the indices of diagonal slice columns",
                                       single_gpu_config("laplacian2d", 1000, "sellp", "f64", variant=16, csr=lap)))
-            picked = single_gpu_config("laplacian2d", 1000, "auto", "f64", csr=lap)
-            others[-1]["auto_choice_this_run"] = {"format": picked["format"], "kernel_variant": picked["variant"],
-                                                  "ms": round(sum(picked["kernel_ms"]) / len(picked["kernel_ms"]), 5)}
             del lap
             torch.cuda.empty_cache()
             rm = generate("rmat", args.rmat_scale)
