@@ -363,8 +363,15 @@ int spmv_hip_bench(spmv_hip_matrix *m, int min_iters, double min_seconds, double
 /* *d_out (double, device) = ||d_x||_2 ; deterministic two-pass reduction on the
  * current device.  The partial sums live in library scratch kept per (device,
  * stream): calls on different streams may overlap; the first call on a
- * (device, stream) pair allocates its 8 KiB. */
+ * (device, stream) pair allocates its 8 KiB, kept until spmv_hip_release_stream
+ * or the end of the process. */
 int spmv_hip_norm2_dev(int n, const void *d_x, int dtype, double *d_out, void *stream);
+/* No counterpart in the reference (it has no streams): gives back what the library
+ * holds on the current device for `stream` -- today the partial sums of
+ * spmv_hip_norm2_dev.  Call it before hipStreamDestroy in a program that creates
+ * and destroys streams; it waits for the stream's work first.  A stream the
+ * library never saw is not an error. */
+int spmv_hip_release_stream(void *stream);
 /* spmv_hip_norm2_dev for callers that cannot allocate (code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
  * reference.  Same kernels and the same bits as spmv_hip_norm2_dev, but the 1024

@@ -65,6 +65,7 @@ SIGNATURES = {
     "spmv_hip_free": (_i, [_vp]),
     "spmv_hip_bench": (_i, [_vp, _i, C.c_double, _vp, C.POINTER(_i), C.POINTER(C.c_double)]),
     "spmv_hip_norm2_dev": (_i, [_i, _vp, _i, _vp, _vp]),
+    "spmv_hip_release_stream": (_i, [_vp]),
     "spmv_hip_norm2_dev_noalloc": (_i, [_i64, _vp, _i, _vp, _vp]),
     "spmv_hip_scale_dev": (_i, [_i, _vp, _vp, _i, _vp, _vp]),
     "spmv_hip_set_option": (_i, [_vp, C.c_char_p, _i64]),

@@ -536,6 +536,11 @@ int spmv_hip_norm2_dev(int n, const void *d_x, int dtype, double *d_out, void *s
     return launch_norm2(n, d_x, dtype, d_out, (hipStream_t)stream);
 }
 
+int spmv_hip_release_stream(void *stream)
+{
+    return release_norm_scratch((hipStream_t)stream);
+}
+
 int spmv_hip_norm2_dev_noalloc(int64_t n, const void *d_x, int dtype, double *d_out, void *stream)
 {
     return launch_norm2_static(n, d_x, dtype, d_out, (hipStream_t)stream);

@@ -146,6 +146,7 @@ bool candidate_keeps_bits(const spmv_hip_matrix *m, int candidate);
 int launch_norm2(int n, const void *d_x, int dtype, double *d_out, hipStream_t stream);
 constexpr int kNormBlocks = 1024;                    // partial sums of the two-pass norm
 // the norm with the caller's own scratch of kNormBlocks doubles (handles that own streams keep one per stream)
+int release_norm_scratch(hipStream_t st);
 int launch_norm2_with(double *partial, int n, const void *d_x, int dtype, double *d_out, hipStream_t stream);
 constexpr int64_t kNormStaticMax = 0x7fffffffLL;     // elements spmv_hip_norm2_dev_noalloc accepts
 int static_scratch_setup();                          // current device's copy of the built-in scratch array

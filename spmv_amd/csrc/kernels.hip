@@ -1709,17 +1709,38 @@ int launch_mult(const spmv_hip_matrix *m, const void *d_x, void *d_y, hipStream_
 
 // Scratch of the two-pass norm: kNormBlocks partial sums.  Launches that may run side by side must
 // not share it, so each (device, stream) pair gets its own, allocated on that pair's first call and
-// kept until the process ends (8 KiB each).
+// kept until the caller releases the stream (release_norm_scratch) or the process ends (8 KiB each).
+static std::mutex norm_scratch_lock;
+static std::map<std::pair<int, hipStream_t>, double *> norm_scratch_of;
+
 static double *norm_scratch(hipStream_t st)
 {
-    static std::mutex lock;
-    static std::map<std::pair<int, hipStream_t>, double *> scratch_of;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> hold(lock);
-    double *&p = scratch_of[std::make_pair(dev, st)];
+    std::lock_guard<std::mutex> hold(norm_scratch_lock);
+    double *&p = norm_scratch_of[std::make_pair(dev, st)];
     if (!p && hipMalloc((void **)&p, kNormBlocks * sizeof(double)) != hipSuccess) p = nullptr;
     return p;
+}
+
+// Frees what the current device holds for `st`; the stream's work is waited for first, since a norm
+// still in flight reads the array.  A stream that never ran a norm is not an error.
+int release_norm_scratch(hipStream_t st)
+{
+    int dev = 0;
+    SPMV_HIP_TRY(hipGetDevice(&dev), return 1);
+    double *p = nullptr;
+    {
+        std::lock_guard<std::mutex> hold(norm_scratch_lock);
+        auto it = norm_scratch_of.find(std::make_pair(dev, st));
+        if (it == norm_scratch_of.end()) return 0;
+        p = it->second;
+        norm_scratch_of.erase(it);
+    }
+    if (!p) return 0;
+    SPMV_HIP_TRY(hipStreamSynchronize(st), return 1);
+    SPMV_HIP_TRY(hipFree(p), return 1);
+    return 0;
 }
 
 int launch_norm2_with(double *partial, int n, const void *d_x, int dtype, double *d_out, hipStream_t st)

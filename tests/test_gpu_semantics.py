@@ -126,6 +126,21 @@ def test_norms_on_two_streams_do_not_share_scratch():
         assert L.spmv_hip_norm2_dev(n // 3, b.data_ptr(), S.F64, outs[3:].data_ptr(), s2.cuda_stream) == 0
         torch.cuda.synchronize()
         assert float(outs[2]) == want_a and float(outs[3]) == want_b
+    # a program that creates and destroys streams gives the per-stream scratch back: free memory does not
+    # shrink over many short-lived streams, and a released stream can be used again
+    assert L.spmv_hip_release_stream(s1.cuda_stream) == 0 and L.spmv_hip_release_stream(s2.cuda_stream) == 0
+    assert L.spmv_hip_release_stream(s1.cuda_stream) == 0            # nothing held: not an error
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info(DEV)[0]
+    for _ in range(600):                                             # 600 x 8 KiB would not show; 600 x a 2 MiB page would
+        s = torch.cuda.Stream(device=DEV)
+        assert L.spmv_hip_norm2_dev(n // 3, b.data_ptr(), S.F64, outs[3:].data_ptr(), s.cuda_stream) == 0
+        assert L.spmv_hip_release_stream(s.cuda_stream) == 0
+    assert float(outs[3]) == want_b
+    assert free_before - torch.cuda.mem_get_info(DEV)[0] < 64 << 20
+    assert L.spmv_hip_norm2_dev(n, a.data_ptr(), S.F64, outs[2:].data_ptr(), s1.cuda_stream) == 0
+    torch.cuda.synchronize()
+    assert float(outs[2]) == want_a
 
 
 def test_exact_order_keeps_the_bits_whatever_the_trial_picks(orc):
