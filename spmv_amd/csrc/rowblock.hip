@@ -167,6 +167,10 @@ __global__ __launch_bounds__(256) void rb_push_kernel(int n, const int *__restri
     int s = 0;
     while (s + 1 < plan.nseg && k >= plan.seg_begin[s + 1]) s++;
     ((T *)plan.dst[s])[k - plan.seg_begin[s]] = x[index[k]];
+    // Another GPU's memory is cached in this GPU's L2 without coherence; the release at the end of a kernel is
+    // only guaranteed to reach this GPU's own scope.  The consumer is ordered behind this kernel by an event,
+    // so the lines have to leave for the consumer's memory before the kernel ends: a system-scope release.
+    __threadfence_system();
 }
 
 // sorted unique values of d_in[0..n) -> *d_out (hipMalloc'ed), *count
