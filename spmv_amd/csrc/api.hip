@@ -483,7 +483,7 @@ int spmv_hip_free(spmv_hip_matrix *m)
     DeviceGuard on(m->device);            // a failed switch still frees: hipFree takes pointers of any device
     release_csr(m);
     void *ptrs[] = {m->d_tile_coord, m->d_row_carry, m->d_val_carry, m->d_nzr_id, m->d_nzr_end, m->d_slice_ptr,
-                    m->d_row_order, m->d_slice_ident, m->d_scol, m->d_sval, m->d_sorted_len, m->d_vop_ptr, m->d_vop_len,
+                    m->d_row_order, m->d_scol, m->d_sval, m->d_sorted_len, m->d_vop_ptr, m->d_vop_len,
                     m->d_x, m->d_y, m->d_norm, m->d_hot_col, m->d_hot_old, m->d_hot_x, m->d_xcd_y, m->d_xcd_presence, m->d_xcd_base, m->d_sdiag, m->d_block_pat, m->d_tile_pat};
     if (m->xcd_sub) spmv_hip_free(m->xcd_sub);
     for (void *p : ptrs)

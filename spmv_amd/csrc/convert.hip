@@ -323,16 +323,6 @@ static int sell_sort_windows(int rows, int64_t window, const int *d_row_ptr, int
     return rc;
 }
 
-// ident[s] = 1 when row_order maps every row of slice s to itself (one wave per slice)
-__global__ __launch_bounds__(kWave) void slice_identity_kernel(int rows, const int *__restrict__ row_order,
-                                                               unsigned char *__restrict__ ident)
-{
-    const int r = blockIdx.x * kWave + threadIdx.x;
-    const bool moved = r < rows && row_order[r] != r;
-    const bool any_moved = __ballot(moved) != 0;
-    if (threadIdx.x == 0) ident[blockIdx.x] = any_moved ? 0 : 1;
-}
-
 // Width of every slice: length of its first row when the rows were sorted
 // (reference sellcs_format.c:152-158), longest row otherwise (sellp.c:411-421,
 // ell.c:72-82).
@@ -739,11 +729,6 @@ int build_sliced(spmv_hip_matrix *m, const int *d_row_ptr, const int *d_col, con
             if (dev_alloc(m, &m->d_row_order, (size_t)rows)) break;
             if (dev_alloc<int>(nullptr, &d_sorted_len, (size_t)rows)) break;
             if (sell_sort_windows(rows, window, d_row_ptr, m->d_row_order, d_sorted_len, st)) break;
-            // slices whose rows all stayed in place need no row_order lookup when y is stored
-            if (dev_alloc(m, &m->d_slice_ident, (size_t)m->nslices)) break;
-            hipLaunchKernelGGL(slice_identity_kernel, dim3((unsigned)m->nslices), dim3(kWave), 0, st, rows, m->d_row_order,
-                               m->d_slice_ident);
-            SPMV_HIP_TRY(hipGetLastError(), break);
         }
         if (m->nslices > 0) {
             if (dev_alloc<int>(nullptr, &d_width, (size_t)m->nslices)) break;

@@ -95,7 +95,6 @@ struct spmv_hip_matrix {
     int64_t sigma = 0;
     int64_t *d_slice_ptr = nullptr; // nslices+1
     int *d_row_order = nullptr;     // rows (SELL only)
-    unsigned char *d_slice_ident = nullptr; // nslices (SELL only): 1 = the slice's rows kept their places
     int *d_scol = nullptr;          // stored
     void *d_sval = nullptr;         // stored (dtype)
     int *d_sdiag = nullptr;         // stored/64 (height 64 only): per slice column, col - row where all its entries

@@ -404,7 +404,6 @@ template <typename T, bool PERM, int U>
 __global__ __launch_bounds__(kBlock) void sliced64_kernel(int rows, int nslices,
                                                           const int64_t *__restrict__ slice_ptr,
                                                           const int *__restrict__ row_order,
-                                                          const unsigned char *__restrict__ slice_ident,
                                                           const int *__restrict__ scol,
                                                           const T *__restrict__ sval,
                                                           const T *__restrict__ x, T *__restrict__ y)
@@ -413,6 +412,9 @@ __global__ __launch_bounds__(kBlock) void sliced64_kernel(int rows, int nslices,
     int s = __builtin_amdgcn_readfirstlane((int)(b * (kBlock / kWave) + threadIdx.x / kWave));
     if (s >= nslices) return;
     int lane = threadIdx.x & (kWave - 1);
+    const int r = s * kWave + lane;
+    // where the result goes: asked for before the stream, so that the store does not wait for a load of its own
+    const int out_row = PERM ? row_order[min(r, rows - 1)] : r;
     int64_t base = slice_ptr[s];
     int width = (int)((slice_ptr[s + 1] - base) >> 6);
     const T *v = sval + base + lane;
@@ -432,9 +434,7 @@ __global__ __launch_bounds__(kBlock) void sliced64_kernel(int rows, int nslices,
         for (int u = 0; u < U; u++) acc = fma_t(xx[u], vv[u], acc);
     }
     for (; j < width; j++) acc = fma_t(x[c[(int64_t)j * kWave]], v[(int64_t)j * kWave], acc);
-    int r = s * kWave + lane;
-    // slices whose rows kept their places (flagged at build time) skip the row_order lookup
-    if (r < rows) y[PERM && !slice_ident[s] ? row_order[r] : r] = acc;
+    if (r < rows) y[out_row] = acc;
 }
 
 // sliced64_wide_kernel: the same slices read with 16-byte loads.  Lane l =
@@ -451,8 +451,7 @@ template <typename T, bool PERM, int U, bool NT>
 __global__ __launch_bounds__(kBlock) void sliced64_wide_kernel(int rows, int nslices,
                                                                const int64_t *__restrict__ slice_ptr,
                                                                const int *__restrict__ row_order,
-                                                               const unsigned char *__restrict__ slice_ident,
-                                                               const int *__restrict__ scol,
+                                                                    const int *__restrict__ scol,
                                                                const T *__restrict__ sval,
                                                                const T *__restrict__ x, T *__restrict__ y)
 {
@@ -466,6 +465,9 @@ __global__ __launch_bounds__(kBlock) void sliced64_wide_kernel(int rows, int nsl
     if (s >= nslices) return;
     const int lane = threadIdx.x & (kWave - 1);
     const int h = lane / HL, q = lane % HL;
+    const int r = s * kWave + lane;
+    // where the result goes: asked for before the stream, so that the store does not wait for a load of its own
+    const int out_row = PERM ? row_order[min(r, rows - 1)] : r;
     int64_t base = slice_ptr[s];
     const int width = (int)((slice_ptr[s + 1] - base) >> 6);
     const T *v = sval + base + q * R;
@@ -518,8 +520,7 @@ __global__ __launch_bounds__(kBlock) void sliced64_wide_kernel(int rows, int nsl
         T from = __shfl(t, lane / R, kWave);
         if ((lane % R) == k) mine = from;
     }
-    int r = s * kWave + lane;
-    if (r < rows) y[PERM && !slice_ident[s] ? row_order[r] : r] = mine;
+    if (r < rows) y[out_row] = mine;
 }
 
 // sliced64_diag_kernel: the exact-order kernel for slices whose columns run along diagonals.  The
@@ -538,7 +539,6 @@ template <typename T, bool PERM, int U, bool NT>
 __global__ __launch_bounds__(kBlock) void sliced64_diag_kernel(int rows, int cols, int nslices,
                                                                const int64_t *__restrict__ slice_ptr,
                                                                const int *__restrict__ row_order,
-                                                               const unsigned char *__restrict__ slice_ident,
                                                                const int *__restrict__ sdiag,
                                                                const int *__restrict__ scol,
                                                                const T *__restrict__ sval,
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(kBlock) void sliced64_diag_kernel(int rows, int col
     if (s >= nslices) return;
     const int lane = threadIdx.x & (kWave - 1);
     const int r = s * kWave + lane;
-    const int row = r < rows ? (PERM && !slice_ident[s] ? row_order[r] : r) : 0;
+    const int row = PERM ? row_order[min(r, rows - 1)] : min(r, rows - 1);
     const int64_t base = slice_ptr[s];
     const int width = (int)((slice_ptr[s + 1] - base) >> 6);
     const T *v = sval + base + lane;
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(kBlock) void sell_dfc_kernel(int rows, int nslices,
     const int *c = scol + slice_ptr[s] + lane;
     const T *v = sval + slice_ptr[s] + lane;
     const int shortest = __builtin_amdgcn_readlane(len, kWave - 1);   // columns below it hold all 64 lanes
-    const int row = DIAG && r < rows ? row_order[r] : 0;
+    const int row = r < rows ? row_order[r] : 0;                // also where y goes: asked for before the stream
     const int *dg = DIAG ? sdiag + vop_ptr[s] : nullptr;
     int run = 0;                                                // entries of the slice before column j
     T acc = 0;
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(kBlock) void sell_dfc_kernel(int rows, int nslices,
             if (j0 + u < len) acc = fma_t(xv, vv[u], acc);
         }
     }
-    if (r < rows) y[DIAG ? row : row_order[r]] = acc;
+    if (r < rows) y[row] = acc;
 }
 
 // The same product with the partial columns staged through LDS.  The columns below the slice's
@@ -684,6 +684,7 @@ __global__ __launch_bounds__(kWave) void sell_dfc_lds_kernel(int rows, int nslic
     const int lane = threadIdx.x;
     const int r = s * kWave + lane;
     const int len = r < rows ? sorted_len[r] : 0;
+    const int out_row = r < rows ? row_order[r] : 0;            // asked for before the stream
     const int width = __builtin_amdgcn_readfirstlane(len);
     const int shortest = __builtin_amdgcn_readlane(len, kWave - 1);
     const int64_t base = slice_ptr[s], slice_end = slice_ptr[s + 1];
@@ -745,7 +746,7 @@ __global__ __launch_bounds__(kWave) void sell_dfc_lds_kernel(int rows, int nslic
         }
         __syncthreads();
     }
-    if (r < rows) y[row_order[r]] = acc;
+    if (r < rows) y[out_row] = acc;
 }
 
 // ------------------------------------- sliced formats, any slice height <= 64 --
@@ -1311,11 +1312,11 @@ static int launch_sliced64(const spmv_hip_matrix *m, const T *x, T *y, hipStream
     const T *sv = (const T *)m->d_sval;
 #define SPMV_WIDE(U, NT)                                                                                   \
     hipLaunchKernelGGL((sliced64_wide_kernel<T, PERM, U, NT>), grid, block, 0, st, m->rows, m->nslices,    \
-                       m->d_slice_ptr, m->d_row_order, m->d_slice_ident, m->d_scol, sv, x, y)
+                       m->d_slice_ptr, m->d_row_order, m->d_scol, sv, x, y)
     switch (m->variant) {
     case 0:
         hipLaunchKernelGGL((sliced64_kernel<T, PERM, 8>), grid, block, 0, st, m->rows, m->nslices, m->d_slice_ptr,
-                           m->d_row_order, m->d_slice_ident, m->d_scol, sv, x, y);
+                           m->d_row_order, m->d_scol, sv, x, y);
         break;
     case 1: SPMV_WIDE(2, false); break;
     case 2: SPMV_WIDE(4, false); break;
@@ -1329,7 +1330,7 @@ static int launch_sliced64(const spmv_hip_matrix *m, const T *x, T *y, hipStream
     case V:                                                                                                \
         if (!m->d_sdiag && m->stored > 0) { set_error("sliced format: variant %d needs the diagonal descriptors", V); return 1; } \
         hipLaunchKernelGGL((sliced64_diag_kernel<T, PERM, U, NT>), grid, block, 0, st, m->rows, m->columns, \
-                           m->nslices, m->d_slice_ptr, m->d_row_order, m->d_slice_ident, m->d_sdiag, m->d_scol, sv, x, y); \
+                           m->nslices, m->d_slice_ptr, m->d_row_order, m->d_sdiag, m->d_scol, sv, x, y); \
         break;
         // 16..19: columns along diagonals are not read (8, 9, 27, 16 columns per batch); 20..23: non-temporal loads
         SPMV_DIAG(16, 8, false)

@@ -31,7 +31,6 @@ template <typename T, bool PERM, int NV, int U, bool NT>
 __global__ __launch_bounds__(kBlock) void sliced64_mv_kernel(int rows, int cols, int nslices,
                                                              const int64_t *__restrict__ slice_ptr,
                                                              const int *__restrict__ row_order,
-                                                             const unsigned char *__restrict__ slice_ident,
                                                              const int *__restrict__ sdiag,
                                                              const int *__restrict__ scol,
                                                              const T *__restrict__ sval,
@@ -47,7 +46,7 @@ __global__ __launch_bounds__(kBlock) void sliced64_mv_kernel(int rows, int cols,
     const T *v = sval + base + lane;
     const int *c = scol + base + lane;
     const int r = s * kWave + lane;
-    const int row = r < rows ? (PERM && !slice_ident[s] ? row_order[r] : r) : 0;
+    const int row = PERM ? row_order[min(r, rows - 1)] : min(r, rows - 1);
     const int *dg = sdiag ? sdiag + (base >> 6) : nullptr;
     const int last = max(cols - 1, 0);
     // the index of entry j of this lane's row: computed for a diagonal column, loaded otherwise.  In a
@@ -287,11 +286,11 @@ static int launch_block(const spmv_hip_matrix *m, const T *x, int64_t ldx, T *y,
             const int *diag = m->d_sdiag && m->diag_columns * 2 * kWave >= m->stored ? m->d_sdiag : nullptr;
             if (perm)
                 hipLaunchKernelGGL((sliced64_mv_kernel<T, true, NV, U, NT>), grid, block, 0, st, m->rows, m->columns,
-                                   m->nslices, m->d_slice_ptr, m->d_row_order, m->d_slice_ident, diag, m->d_scol, sv, x,
+                                   m->nslices, m->d_slice_ptr, m->d_row_order, diag, m->d_scol, sv, x,
                                    ldx, y, ldy);
             else
                 hipLaunchKernelGGL((sliced64_mv_kernel<T, false, NV, U, NT>), grid, block, 0, st, m->rows, m->columns,
-                                   m->nslices, m->d_slice_ptr, m->d_row_order, m->d_slice_ident, diag, m->d_scol, sv, x,
+                                   m->nslices, m->d_slice_ptr, m->d_row_order, diag, m->d_scol, sv, x,
                                    ldx, y, ldy);
         } else {
             const dim3 grid(blocks_for(m->rows, kBlock)), block(kBlock);
