@@ -764,6 +764,7 @@ __global__ __launch_bounds__(kBlock) void sliced_any_kernel(int rows, int height
     int r = (int)(b * kBlock + threadIdx.x);
     if (r >= rows) return;
     int s = r / height, k = r - s * height;
+    const int out_row = PERM ? row_order[r] : r;
     int64_t base = slice_ptr[s];
     int width = (int)((slice_ptr[s + 1] - base) / height);
     T acc = 0;
@@ -771,7 +772,7 @@ __global__ __launch_bounds__(kBlock) void sliced_any_kernel(int rows, int height
         int64_t at = base + (int64_t)j * height + k;
         acc = fma_t(x[scol[at]], sval[at], acc);
     }
-    y[PERM ? row_order[r] : r] = acc;
+    y[out_row] = acc;
 }
 
 // ------------------------------------------------ merge-path / balanced tiles --
