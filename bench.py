@@ -769,19 +769,25 @@ def main(argv=None):
             tt = torch.tensor([a.elapsed_time(b) / reps], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return float(tt.item())
-        exchange_ms = timed_ms(op.exchange_only)
-        compute_ms = timed_ms(lambda: op.compute_only(y))
-        comm = {"exchange_alone_ms": round(exchange_ms, 5), "local_products_alone_ms": round(compute_ms, 5),
-                "halo_entries_rank0": int(op.nhalo), "backend": backend,
-                "collectives": "batch_isend_irecv (one group of peer-to-peer sends/receives per product)"
-                               if args.exchange == "halo" else "all_gather_into_tensor of x"}
+        try:
+            exchange_ms = timed_ms(op.exchange_only)
+            compute_ms = timed_ms(lambda: op.compute_only(y))
+            comm = {"exchange_alone_ms": round(exchange_ms, 5), "local_products_alone_ms": round(compute_ms, 5),
+                    "halo_entries_rank0": int(op.nhalo), "backend": backend,
+                    "collectives": "batch_isend_irecv (one group of peer-to-peer sends/receives per product)"
+                                   if args.exchange == "halo" else "all_gather_into_tensor of x"}
+        except Exception as e:                # the breakdown is an extra: the timed result above stands without it
+            comm = {"error": f"{type(e).__name__}: {e}"[:300]}
     # what the communicator itself reports: every rank contributes its device to one all-gather
     mine = torch.tensor([dev_index], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
     seen = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(seen, mine)
+    try:
+        rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+    except Exception as e:                    # a version query must never cost the result line
+        rccl_version = f"unavailable ({type(e).__name__})"
     rccl = {"world": dist.get_world_size(), "backend": dist.get_backend(), "ranks_seen": len(seen),
-            "devices_of_ranks": [int(v.item()) for v in seen],
-            "version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None}
+            "devices_of_ranks": [int(v.item()) for v in seen], "version": rccl_version}
     b_alg = algorithmic_bytes(rows, rows, nnz, vbytes)        # one launch group, this GPU's slab
     key = f"{args.format}/{args.matrix}/{n}/{args.dtype}/gpus{world}/variant{variant}"
     out = None
@@ -801,7 +807,8 @@ def main(argv=None):
             "rccl": rccl,
         }
         if comm is not None:
-            comm["exposed_ms"] = round(max(ms_per_step - comm["local_products_alone_ms"], 0.0), 5)
+            if "error" not in comm:
+                comm["exposed_ms"] = round(max(ms_per_step - comm["local_products_alone_ms"], 0.0), 5)
             out["communication"] = comm
     # the ranks are done: release the GPUs, then (rank 0) the same slabs from one process through the C ABI
     del op, x, y

@@ -818,6 +818,8 @@ static int dist_finish(spmv_hip_dist *d)
     std::vector<std::vector<int>> halo(P);
     const char *require = getenv("SPMV_REQUIRE_P2P");
     const bool require_p2p = require && atoi(require) != 0;
+    // peer access for every pair first, before any of the vectors below exists: every allocation the pushes
+    // write to is then made with the access already in place
     for (int q = 0; q < P; q++) {
         SPMV_HIP_TRY(hipSetDevice(d->device[q]), return 1);
         // pushes go from q's communication stream into p's memory: q needs access to p
@@ -840,6 +842,9 @@ static int dist_finish(spmv_hip_dist *d)
                         d->device[q], d->device[p], q, p);
             }
         }
+    }
+    for (int q = 0; q < P; q++) {
+        SPMV_HIP_TRY(hipSetDevice(d->device[q]), return 1);
         const int n = d->block[q]->rows, nh = d->block[q]->halo;
         halo[q].resize((size_t)nh);
         if (spmv_hip_rowblock_halo_columns(d->block[q], halo[q].data())) return 1;
