@@ -461,6 +461,8 @@ def traffic_key(fmt_name, matrix, n, dtype_name, world, info):
         v += "+hot1"
     elif info.hot_columns == 2:
         v += f"+hot2tiles{info.hot_variant}"
+    if info.block_map and info.hot_columns != 2:
+        v += f"+map{info.block_map}"
     return f"{fmt_name}/{matrix}/{n}/{dtype_name}/gpus{world}/{v}"
 
 
@@ -613,7 +615,7 @@ def main(argv=None):
         b_alg = algorithmic_bytes(rows, cols, nnz, vbytes)
         res = {"workload": workload, "format": fmt_name, "fmt": fmt, "dtype": dtype_name, "rows": rows, "cols": cols, "nnz": nnz,
                "stored": int(info.stored), "variant": info.variant, "lanes_per_row": info.lanes_per_row,
-               "hot_columns": info.hot_columns, "hot_variant": info.hot_variant, "elapsed": elapsed, "kernel_ms": kernel_ms,
+               "hot_columns": info.hot_columns, "hot_variant": info.hot_variant, "block_map": info.block_map, "elapsed": elapsed, "kernel_ms": kernel_ms,
                "b_alg": b_alg, "key": traffic_key(fmt_name, matrix, n, dtype_name, 1, info), "general": None}
         # outside the timed region: the fastest variant of the same handle that reads every column index
         # (what a matrix without grid structure gets), measured the same way
@@ -625,10 +627,18 @@ def main(argv=None):
                 trial[v] = ms[len(ms) // 2]
             gv = min(trial, key=trial.get)
             m.set_option("variant", gv)
+            other = {}
+            for bm in (0, 1, 3, 5, 7):        # and the fastest way of dealing the workgroups over the matrix
+                m.set_option("block_map", bm)
+                _, ms = timed_region(step, 5, 2)
+                other[bm] = ms[len(ms) // 2]
+            m.set_option("block_map", min(other, key=other.get))
             _, gms = timed_region(step, steps, warmup)
             gkey = traffic_key(fmt_name, matrix, n, dtype_name, 1, m.info)
             res["general"] = roofline_record(b_alg, sum(gms) / len(gms), gms, gkey, gv)
+            res["general"]["block_map"] = m.info.block_map
             m.set_option("variant", info.variant)
+            m.set_option("block_map", info.block_map)
         m.free()
         del x, y
         torch.cuda.empty_cache()
@@ -640,7 +650,7 @@ def main(argv=None):
         mean = sum(ms) / len(ms)
         rec = roofline_record(res["b_alg"], mean, ms, res["key"], res["variant"])
         entry = {"config": name, "workload": res["workload"], "format": res["format"], "dtype": res["dtype"],
-                 "rows": res["rows"], "nnz": res["nnz"], "kernel_variant": res["variant"], "hot_columns": res["hot_columns"],
+                 "rows": res["rows"], "nnz": res["nnz"], "kernel_variant": res["variant"], "block_map": res["block_map"], "hot_columns": res["hot_columns"],
                  "ms": round(mean, 5), "ms_median": rec["kernel_ms_median"], "gflops": round(2.0 * res["nnz"] / mean / 1e6, 1),
                  "frac": rec["frac"], "algorithmic_bytes_per_launch": res["b_alg"], "traffic": rec["traffic"],
                  "frac_moved": rec["frac_moved"], "traffic_key": res["key"]}
@@ -682,7 +692,7 @@ def main(argv=None):
             "config": {"workload": res["workload"], "format": args.format,
                        "params": {"C": 64, "sigma": args.sigma} if fmt == S.SELL else {"p0": args.p0},
                        "rows": res["rows"], "nnz": res["nnz"], "stored_per_gpu": res["stored"], "kernel_variant": res["variant"],
-                       "hot_columns": res["hot_columns"], "exchange": None},
+                       "block_map": res["block_map"], "hot_columns": res["hot_columns"], "exchange": None},
             "roofline": roofline_record(res["b_alg"], mean_kernel_ms, kernel_ms, res["key"], res["variant"]),
         }
         if res["general"] is not None:

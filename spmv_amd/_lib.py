@@ -25,7 +25,8 @@ class Info(C.Structure):
                 ("nnz", C.c_int64), ("stored", C.c_int64), ("slice_height", C.c_int),
                 ("sigma", C.c_int64), ("nslices", C.c_int), ("lanes_per_row", C.c_int),
                 ("ntiles", C.c_int), ("items_per_tile", C.c_int), ("device_bytes", C.c_int64),
-                ("variant", C.c_int), ("hot_columns", C.c_int), ("diag_columns", C.c_int64), ("pattern_blocks", C.c_int), ("hot_variant", C.c_int)]
+                ("variant", C.c_int), ("hot_columns", C.c_int), ("diag_columns", C.c_int64), ("pattern_blocks", C.c_int), ("hot_variant", C.c_int),
+                ("block_map", C.c_int)]
 
 
 class RowBlockInfo(C.Structure):

@@ -642,6 +642,11 @@ int spmv_hip_set_option(spmv_hip_matrix *m, const char *name, int64_t value)
     DeviceGuard on(m->device);
     if (!on.ok) return 1;
     if (!strcmp(name, "variant")) { m->variant = (int)value; return 0; }
+    if (!strcmp(name, "block_map")) {
+        if (value < 0 || value > (1 << 20)) { set_error("block_map takes 0, 1 or a run length up to 2^20"); return 1; }
+        m->block_map = (int)value;
+        return 0;
+    }
     if (!strcmp(name, "hot_variant")) {                     // the tile kernel of the stacked matrix behind hot_columns 2
         if (!m->xcd_sub) { set_error("hot_variant needs hot_columns 2"); return 1; }
         int cand[32];
@@ -690,6 +695,12 @@ int spmv_hip_set_row_map(spmv_hip_matrix *m, const int *d_row_map)
 // Times every kernel variant of the handle `reps` times and keeps the fastest; *best_ms_out (optional)
 // receives the summed time of the winner's `reps` launches (handles with a single variant are timed
 // only when the caller asks for the time).
+// Values of the option "block_map" a kernel trial compares: an eighth of the matrix per XCD, consecutive
+// workgroups on consecutive pieces, and short runs of workgroups per XCD -- odd run lengths keep the eight
+// XCDs' streams from meeting on the same memory channels (27-point stencil 252^3, SELL-64-1024, fp64:
+// 0.803 ms with 0, 0.794 with 1, 0.761 with 5).
+static const int kBlockMapCandidates[] = {0, 1, 3, 5, 7};
+
 static int analyze_impl(spmv_hip_matrix *m, int reps, float *best_ms_out)
 {
     if (best_ms_out) *best_ms_out = 0;
@@ -730,19 +741,46 @@ static int analyze_impl(spmv_hip_matrix *m, int reps, float *best_ms_out)
             return 0;
         }
     }
-    bool first = true;
-    for (int i = 0; i < n && !rc; i++) {
-        apply(cand[i]);
-        if (launch_mult(m, m->d_x, m->d_y, nullptr)) { rc = 1; break; }          // warm-up
-        float total = 0;
+    // one warm-up launch, then `reps` timed ones of the handle as it is set
+    auto time_current = [&](float *total) {
+        if (launch_mult(m, m->d_x, m->d_y, nullptr)) return 1;
+        *total = 0;
         for (int r = 0; r < reps; r++) {
             if (hipEventRecord(e0, nullptr) != hipSuccess || launch_mult(m, m->d_x, m->d_y, nullptr) ||
-                hipEventRecord(e1, nullptr) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) { rc = 1; break; }
+                hipEventRecord(e1, nullptr) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)
+                return 1;
             float ms = 0;
-            if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = 1; break; }
-            total += ms;
+            if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return 1;
+            *total += ms;
         }
-        if (!rc && (first || total < best_ms)) { best_ms = total; best = cand[i]; first = false; }
+        return 0;
+    };
+    bool first = true;
+    auto pick_variant = [&]() {
+        for (int i = 0; i < n && !rc; i++) {
+            apply(cand[i]);
+            float total = 0;
+            rc = time_current(&total);
+            if (!rc && (first || total < best_ms)) { best_ms = total; best = cand[i]; first = false; }
+        }
+    };
+    pick_variant();
+    // then the winner with its workgroups dealt over the matrix in other ways (option "block_map"; the
+    // result's bits do not depend on it), and, when another way wins, the variants once more under it.
+    // Not for the stacked matrix behind hot_columns 2: there each XCD has to stay with its column group.
+    if (!rc && !first && !m->xcd_sub && m->group_cpx == 0) {
+        const int keep_map = m->block_map;
+        int best_map = keep_map;
+        apply(best);
+        for (int map : kBlockMapCandidates) {
+            if (map == keep_map) continue;
+            m->block_map = map;
+            float total = 0;
+            if ((rc = time_current(&total))) break;
+            if (total < best_ms) { best_ms = total; best_map = map; }
+        }
+        m->block_map = rc ? keep_map : best_map;
+        if (!rc && best_map != keep_map && n > 1) pick_variant();
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -887,6 +925,7 @@ int spmv_hip_get_info(const spmv_hip_matrix *m, spmv_hip_info *info)
     info->diag_columns = m->diag_columns;
     info->pattern_blocks = m->pat_blocks;
     info->hot_variant = m->xcd_sub ? m->xcd_sub->variant : 0;
+    info->block_map = m->block_map;
     return 0;
 }
 

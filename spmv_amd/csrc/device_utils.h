@@ -17,4 +17,17 @@ __device__ __forceinline__ unsigned xcd_contiguous_block(unsigned bid, unsigned 
     return base + idx;
 }
 
+// `map` (option "block_map"): 0 = one contiguous eighth of the blocks per XCD (above); 1 = logical block =
+// hardware block id (consecutive workgroups, which land on different XCDs, walk consecutive pieces of the
+// matrix); K > 1 = runs of K consecutive logical blocks dealt over the XCDs in turn (the blocks past the last
+// full round of 8 K keep their own number).  Bijective for any grid size.
+__device__ __forceinline__ unsigned xcd_block(unsigned bid, unsigned nblocks, int map)
+{
+    if (map == 0) return xcd_contiguous_block(bid, nblocks);
+    const unsigned k = (unsigned)map, round = 8u * k;
+    if (k == 1 || bid >= nblocks / round * round) return bid;
+    const unsigned g = bid & 7u, idx = bid >> 3;          // XCD, and the block's number among that XCD's blocks
+    return (idx / k * 8u + g) * k + idx % k;
+}
+
 } // namespace spmv

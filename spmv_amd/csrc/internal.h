@@ -72,6 +72,8 @@ struct spmv_hip_matrix {
                                           // rows repeat one pattern of distances from the diagonal, else 0
     int pat_blocks = 0;            // how many blocks do
     int variant = 0;               // kernel variant inside the format (spmv_hip_set_option "variant")
+    int block_map = 0;             // 0: every XCD walks one contiguous eighth of the matrix; 1: consecutive workgroups
+                                   // walk consecutive pieces (spmv_hip_set_option "block_map")
     bool exact_order = false;      // spmv_hip_analyze may only pick variants that leave y's bits as they are
     double max_padding = 0;        // > 0: building a sliced layout fails when stored > max_padding * nnz
 

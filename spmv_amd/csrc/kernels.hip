@@ -68,9 +68,9 @@ __global__ __launch_bounds__(kBlock) void csr_scalar_kernel(int rows, const int 
                                                             const int *__restrict__ col,
                                                             const T *__restrict__ val,
                                                             const int *__restrict__ row_map,
-                                                            const T *__restrict__ x, T *__restrict__ y)
+                                                            const T *__restrict__ x, T *__restrict__ y, int plain)
 {
-    unsigned b = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    unsigned b = xcd_block(blockIdx.x, gridDim.x, plain);
     int row = (int)(b * kBlock + threadIdx.x);
     if (row >= rows) return;
     int beg = row_ptr[row], end = row_ptr[row + 1];
@@ -95,11 +95,11 @@ __global__ __launch_bounds__(kWave) void csr_rows_lds_kernel(int rows, const int
                                                              const int *__restrict__ col,
                                                              const T *__restrict__ val,
                                                              const int *__restrict__ row_map,
-                                                             const T *__restrict__ x, T *__restrict__ y)
+                                                             const T *__restrict__ x, T *__restrict__ y, int plain)
 {
     constexpr int kCap = kWave * IPL;
     __shared__ xv_pair<T> stage[kCap];
-    const int blk = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int blk = (int)xcd_block(blockIdx.x, gridDim.x, plain);
     const int lane = threadIdx.x;
     const int row = blk * kWave + lane;
     const int last = min(blk * kWave + kWave, rows);
@@ -169,12 +169,12 @@ __global__ __launch_bounds__(kWave) void csr_rows_lds_pat_kernel(int rows, const
                                                                  const T *__restrict__ val,
                                                                  const unsigned char *__restrict__ pattern_len,
                                                                  const int *__restrict__ row_map,
-                                                                 const T *__restrict__ x, T *__restrict__ y)
+                                                                 const T *__restrict__ x, T *__restrict__ y, int plain)
 {
     constexpr int kCap = kWave * IPL;
     __shared__ xv_pair<T> stage[kCap];
     __shared__ int dist[32];
-    const int blk = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int blk = (int)xcd_block(blockIdx.x, gridDim.x, plain);
     const int lane = threadIdx.x;
     const int row0 = blk * kWave;
     const int row = row0 + lane;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(kBlock) void csr_vector_kernel(int rows, const int 
                                                             const int *__restrict__ col,
                                                             const T *__restrict__ val,
                                                             const int *__restrict__ row_map,
-                                                            const T *__restrict__ x, T *__restrict__ y)
+                                                            const T *__restrict__ x, T *__restrict__ y, int plain)
 {
     static_assert(R <= G, "the first R lanes of a group store its R rows");
     constexpr int kRowsPerBlock = kBlock / G * R;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(kBlock) void csr_vector_kernel(int rows, const int 
     const unsigned nblocks = (unsigned)((rows + kRowsPerBlock - 1) / kRowsPerBlock);
     const unsigned bid = blockIdx.y * gridDim.x + blockIdx.x;
     if (bid >= nblocks) return;
-    const unsigned b = xcd_contiguous_block(bid, nblocks);
+    const unsigned b = xcd_block(bid, nblocks, plain);
     const int lane = threadIdx.x % G;
     const int row0 = (int)(b * kRowsPerBlock) + (int)(threadIdx.x / G) * R;
     int ptr[R + 1];
@@ -308,12 +308,12 @@ __global__ __launch_bounds__(kWave) void csr_vector_lds_kernel(int rows, const i
                                                                const T *__restrict__ val,
                                                                const unsigned char *__restrict__ pattern_len,
                                                                const int *__restrict__ row_map,
-                                                               const T *__restrict__ x, T *__restrict__ y)
+                                                               const T *__restrict__ x, T *__restrict__ y, int plain)
 {
     constexpr int kCap = kWave * IPL, kRowsPerPass = kWave / G;
     __shared__ T prod[kCap];
     __shared__ int dist[32];
-    const int blk = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int blk = (int)xcd_block(blockIdx.x, gridDim.x, plain);
     const int lane = threadIdx.x, sub = lane % G;
     const int row = blk * kWave + lane;
     const int last = min(blk * kWave + kWave, rows);
@@ -406,9 +406,9 @@ __global__ __launch_bounds__(kBlock) void sliced64_kernel(int rows, int nslices,
                                                           const int *__restrict__ row_order,
                                                           const int *__restrict__ scol,
                                                           const T *__restrict__ sval,
-                                                          const T *__restrict__ x, T *__restrict__ y)
+                                                          const T *__restrict__ x, T *__restrict__ y, int plain)
 {
-    unsigned b = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    unsigned b = xcd_block(blockIdx.x, gridDim.x, plain);
     int s = __builtin_amdgcn_readfirstlane((int)(b * (kBlock / kWave) + threadIdx.x / kWave));
     if (s >= nslices) return;
     int lane = threadIdx.x & (kWave - 1);
@@ -453,14 +453,14 @@ __global__ __launch_bounds__(kBlock) void sliced64_wide_kernel(int rows, int nsl
                                                                const int *__restrict__ row_order,
                                                                     const int *__restrict__ scol,
                                                                const T *__restrict__ sval,
-                                                               const T *__restrict__ x, T *__restrict__ y)
+                                                               const T *__restrict__ x, T *__restrict__ y, int plain)
 {
     constexpr int R = 16 / sizeof(T);        // rows per lane: 2 (fp64), 4 (fp32)
     constexpr int HL = kWave / R;            // lanes per column: 32, 16
     constexpr int P = R;                     // columns per wave instruction: 2, 4
     typedef T TV __attribute__((ext_vector_type(R)));
     typedef int IV __attribute__((ext_vector_type(R)));
-    unsigned b = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    unsigned b = xcd_block(blockIdx.x, gridDim.x, plain);
     int s = __builtin_amdgcn_readfirstlane((int)(b * (kBlock / kWave) + threadIdx.x / kWave));
     if (s >= nslices) return;
     const int lane = threadIdx.x & (kWave - 1);
@@ -542,9 +542,9 @@ __global__ __launch_bounds__(kBlock) void sliced64_diag_kernel(int rows, int col
                                                                const int *__restrict__ sdiag,
                                                                const int *__restrict__ scol,
                                                                const T *__restrict__ sval,
-                                                               const T *__restrict__ x, T *__restrict__ y)
+                                                               const T *__restrict__ x, T *__restrict__ y, int plain)
 {
-    unsigned b = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    unsigned b = xcd_block(blockIdx.x, gridDim.x, plain);
     int s = __builtin_amdgcn_readfirstlane((int)(b * (kBlock / kWave) + threadIdx.x / kWave));
     if (s >= nslices) return;
     const int lane = threadIdx.x & (kWave - 1);
@@ -605,9 +605,9 @@ __global__ __launch_bounds__(kBlock) void sell_dfc_kernel(int rows, int nslices,
                                                           const T *__restrict__ sval,
                                                           const T *__restrict__ x, T *__restrict__ y,
                                                           const int64_t *__restrict__ vop_ptr = nullptr,
-                                                          const int *__restrict__ sdiag = nullptr)
+                                                          const int *__restrict__ sdiag = nullptr, int plain = 0)
 {
-    unsigned b = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    unsigned b = xcd_block(blockIdx.x, gridDim.x, plain);
     int s = __builtin_amdgcn_readfirstlane((int)(b * (kBlock / kWave) + threadIdx.x / kWave));
     if (s >= nslices) return;
     const int lane = threadIdx.x & (kWave - 1);
@@ -676,11 +676,11 @@ __global__ __launch_bounds__(kWave) void sell_dfc_lds_kernel(int rows, int nslic
                                                              const int *__restrict__ row_order,
                                                              const int *__restrict__ scol,
                                                              const T *__restrict__ sval,
-                                                             const T *__restrict__ x, T *__restrict__ y)
+                                                             const T *__restrict__ x, T *__restrict__ y, int plain)
 {
     constexpr int kCap = kWave * IPL, U = 8;
     __shared__ xv_pair<T> stage[kCap];
-    const int s = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int s = (int)xcd_block(blockIdx.x, gridDim.x, plain);
     const int lane = threadIdx.x;
     const int r = s * kWave + lane;
     const int len = r < rows ? sorted_len[r] : 0;
@@ -758,9 +758,9 @@ __global__ __launch_bounds__(kBlock) void sliced_any_kernel(int rows, int height
                                                             const int *__restrict__ row_order,
                                                             const int *__restrict__ scol,
                                                             const T *__restrict__ sval,
-                                                            const T *__restrict__ x, T *__restrict__ y)
+                                                            const T *__restrict__ x, T *__restrict__ y, int plain)
 {
-    unsigned b = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    unsigned b = xcd_block(blockIdx.x, gridDim.x, plain);
     int r = (int)(b * kBlock + threadIdx.x);
     if (r >= rows) return;
     int s = r / height, k = r - s * height;
@@ -807,13 +807,13 @@ __global__ __launch_bounds__(kWave) void wave_tile_kernel(int list_len, const in
                                                           const int *__restrict__ col,
                                                           const T *__restrict__ val,
                                                           const T *__restrict__ x, T *__restrict__ y,
-                                                          int *__restrict__ row_carry, T *__restrict__ val_carry)
+                                                          int *__restrict__ row_carry, T *__restrict__ val_carry, int plain)
 {
     constexpr int kCap = kWave * IPL;
     __shared__ T prod[kCap];
     __shared__ int rend[kCap];
     __shared__ int dist[32];
-    const int t = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int t = (int)xcd_block(blockIdx.x, gridDim.x, plain);
     const int lane = threadIdx.x;
     const int a0 = tile_coord[2 * t], b0 = tile_coord[2 * t + 1];
     const int a1 = tile_coord[2 * t + 2], b1 = tile_coord[2 * t + 3];
@@ -1185,10 +1185,10 @@ template <typename T> static int launch_csr_vector(const spmv_hip_matrix *m, con
     case G:                                                                                           \
         if (!nt)                                                                                      \
             hipLaunchKernelGGL((csr_vector_lds_kernel<T, 8, G, false>), grid, block, 0, st, rows, rp, cj, va, pat, \
-                               m->d_row_map, x, y);                                                   \
+                               m->d_row_map, x, y, m->block_map);                                                   \
         else                                                                                          \
             hipLaunchKernelGGL((csr_vector_lds_kernel<T, 8, G, true>), grid, block, 0, st, rows, rp, cj, va, pat, \
-                               m->d_row_map, x, y);                                                   \
+                               m->d_row_map, x, y, m->block_map);                                                   \
         return 0;
         switch (g) {
             SPMV_VECLDS(2)
@@ -1204,7 +1204,7 @@ template <typename T> static int launch_csr_vector(const spmv_hip_matrix *m, con
 #define SPMV_VEC_ONE(G, R)                                                                            \
     case G * 16 + R:                                                                                  \
         hipLaunchKernelGGL((csr_vector_kernel<T, G, R>), folded_grid(cdiv(rows, kBlock / G * R)), dim3(kBlock), 0, \
-                           st, rows, rp, cj, va, m->d_row_map, x, y);                                 \
+                           st, rows, rp, cj, va, m->d_row_map, x, y, m->block_map);                   \
         break;
 #define SPMV_VEC_CASE(G) SPMV_VEC_ONE(G, 1) SPMV_VEC_ONE(G, 2) SPMV_VEC_ONE(G, 4) SPMV_VEC_ONE(G, 8)
     switch (m->lanes_per_row * 16 + side) {
@@ -1313,11 +1313,11 @@ static int launch_sliced64(const spmv_hip_matrix *m, const T *x, T *y, hipStream
     const T *sv = (const T *)m->d_sval;
 #define SPMV_WIDE(U, NT)                                                                                   \
     hipLaunchKernelGGL((sliced64_wide_kernel<T, PERM, U, NT>), grid, block, 0, st, m->rows, m->nslices,    \
-                       m->d_slice_ptr, m->d_row_order, m->d_scol, sv, x, y)
+                       m->d_slice_ptr, m->d_row_order, m->d_scol, sv, x, y, m->block_map)
     switch (m->variant) {
     case 0:
         hipLaunchKernelGGL((sliced64_kernel<T, PERM, 8>), grid, block, 0, st, m->rows, m->nslices, m->d_slice_ptr,
-                           m->d_row_order, m->d_scol, sv, x, y);
+                           m->d_row_order, m->d_scol, sv, x, y, m->block_map);
         break;
     case 1: SPMV_WIDE(2, false); break;
     case 2: SPMV_WIDE(4, false); break;
@@ -1331,7 +1331,7 @@ static int launch_sliced64(const spmv_hip_matrix *m, const T *x, T *y, hipStream
     case V:                                                                                                \
         if (!m->d_sdiag && m->stored > 0) { set_error("sliced format: variant %d needs the diagonal descriptors", V); return 1; } \
         hipLaunchKernelGGL((sliced64_diag_kernel<T, PERM, U, NT>), grid, block, 0, st, m->rows, m->columns, \
-                           m->nslices, m->d_slice_ptr, m->d_row_order, m->d_sdiag, m->d_scol, sv, x, y); \
+                           m->nslices, m->d_slice_ptr, m->d_row_order, m->d_sdiag, m->d_scol, sv, x, y, m->block_map); \
         break;
         // 16..19: columns along diagonals are not read (8, 9, 27, 16 columns per batch); 20..23: non-temporal loads
         SPMV_DIAG(16, 8, false)
@@ -1356,18 +1356,18 @@ template <typename T> static int launch_sell_dfc(const spmv_hip_matrix *m, const
 #define SPMV_DFC(V, U, NT)                                                                               \
     case V:                                                                                              \
         hipLaunchKernelGGL((sell_dfc_kernel<T, U, NT>), grid, block, 0, st, m->rows, m->nslices, m->d_slice_ptr, \
-                           m->d_sorted_len, m->d_row_order, m->d_scol, sv, x, y);                        \
+                           m->d_sorted_len, m->d_row_order, m->d_scol, sv, x, y, nullptr, nullptr, m->block_map); \
         break;
 #define SPMV_DFC_LDS(V, I, NT)                                                                           \
     case V:                                                                                              \
         hipLaunchKernelGGL((sell_dfc_lds_kernel<T, I, NT>), dim3((unsigned)m->nslices), dim3(kWave), 0, st, m->rows, \
-                           m->nslices, m->d_slice_ptr, m->d_sorted_len, m->d_row_order, m->d_scol, sv, x, y); \
+                           m->nslices, m->d_slice_ptr, m->d_sorted_len, m->d_row_order, m->d_scol, sv, x, y, m->block_map); \
         break;
 #define SPMV_DFC_DIAG(V, U, NT)                                                                          \
     case V:                                                                                              \
         if (!m->d_sdiag) { set_error("sell_dfc: variant %d needs the diagonal descriptors", V); return 1; } \
         hipLaunchKernelGGL((sell_dfc_kernel<T, U, NT, true>), grid, block, 0, st, m->rows, m->nslices, m->d_slice_ptr, \
-                           m->d_sorted_len, m->d_row_order, m->d_scol, sv, x, y, m->d_vop_ptr, m->d_sdiag); \
+                           m->d_sorted_len, m->d_row_order, m->d_scol, sv, x, y, m->d_vop_ptr, m->d_sdiag, m->block_map); \
         break;
     // 0..4: partial columns as masked loads (8, 16, 8 nt, 16 nt, 4 columns per batch);
     // 5..8: partial columns staged through LDS (chunks of 512, 512 nt, 256, 1024 entries);
@@ -1404,10 +1404,10 @@ template <typename T> static int launch_sliced(const spmv_hip_matrix *m, const T
         dim3 grid(cdiv(m->rows, kBlock));
         if (perm)
             hipLaunchKernelGGL((sliced_any_kernel<T, true>), grid, dim3(kBlock), 0, st, m->rows, m->slice_height,
-                               m->d_slice_ptr, m->d_row_order, m->d_scol, sv, x, y);
+                               m->d_slice_ptr, m->d_row_order, m->d_scol, sv, x, y, m->block_map);
         else
             hipLaunchKernelGGL((sliced_any_kernel<T, false>), grid, dim3(kBlock), 0, st, m->rows, m->slice_height,
-                               m->d_slice_ptr, m->d_row_order, m->d_scol, sv, x, y);
+                               m->d_slice_ptr, m->d_row_order, m->d_scol, sv, x, y, m->block_map);
     }
     return 0;
 }
@@ -1421,7 +1421,7 @@ template <typename T> static int launch_csr_scalar(const spmv_hip_matrix *m, con
 #define SPMV_ROWS_ONE(V, I, NT)                                                                          \
     case V:                                                                                              \
         hipLaunchKernelGGL((csr_rows_lds_kernel<T, I, NT>), grid, block, 0, st, m->rows, m->d_row_ptr, m->d_col, \
-                           va, m->d_row_map, x, y);                                                      \
+                           va, m->d_row_map, x, y, m->block_map);                                                      \
         break;
 #define SPMV_ROWS_CASE(V, I) SPMV_ROWS_ONE(V, I, false) SPMV_ROWS_ONE(V + 8, I, true)
     // a matrix without entries has no patterns to read: any chunked kernel writes its zeros
@@ -1432,13 +1432,13 @@ template <typename T> static int launch_csr_scalar(const spmv_hip_matrix *m, con
         SPMV_ROWS_CASE(4, 32)
     case 1:
         hipLaunchKernelGGL((csr_scalar_kernel<T>), dim3(cdiv(m->rows, kBlock)), dim3(kBlock), 0, st, m->rows,
-                           m->d_row_ptr, m->d_col, va, m->d_row_map, x, y);
+                           m->d_row_ptr, m->d_col, va, m->d_row_map, x, y, m->block_map);
         break;
 #define SPMV_ROWS_PAT(V, I, NT)                                                                          \
     case V:                                                                                              \
         if (!m->d_block_pat) { set_error("scalar CSR: variant %d needs the block patterns", V); return 1; } \
         hipLaunchKernelGGL((csr_rows_lds_pat_kernel<T, I, NT>), grid, block, 0, st, m->rows, m->d_row_ptr, m->d_col, \
-                           va, m->d_block_pat, m->d_row_map, x, y);                                      \
+                           va, m->d_block_pat, m->d_row_map, x, y, m->block_map);                                      \
         break;
         // 16..18: patterned row blocks read one row's column indices (512, 1024, 256 entries per chunk); 20..22: non-temporal
         SPMV_ROWS_PAT(16, 8, false)
@@ -1503,10 +1503,10 @@ template <typename T> static int launch_tiles(const spmv_hip_matrix *m, const T 
     case I:                                                                                              \
         if (m->variant == 0)                                                                             \
             hipLaunchKernelGGL((wave_tile_kernel<T, I, 0>), dim3(m->ntiles), dim3(kWave), 0, st, list_len, list, \
-                               index, m->d_tile_coord, pat, m->d_col, va, x, y, m->d_row_carry, vc);     \
+                               index, m->d_tile_coord, pat, m->d_col, va, x, y, m->d_row_carry, vc, m->group_cpx > 0 ? 0 : m->block_map);     \
         else                                                                                             \
             hipLaunchKernelGGL((wave_tile_kernel<T, I, 2>), dim3(m->ntiles), dim3(kWave), 0, st, list_len, list, \
-                               index, m->d_tile_coord, pat, m->d_col, va, x, y, m->d_row_carry, vc);     \
+                               index, m->d_tile_coord, pat, m->d_col, va, x, y, m->d_row_carry, vc, m->group_cpx > 0 ? 0 : m->block_map);     \
         break;
     switch (m->items_per_tile % kWave ? 0 : m->items_per_tile / kWave) {
         SPMV_WTILE_CASE(4)

@@ -108,6 +108,12 @@ def test_c2_stencil_252_against_the_oracle(orc):
     for v in EXACT_SLICED:
         sell.set_option("variant", v)
         assert _mult(sell, x, rows).cpu().numpy().tobytes() == want.tobytes(), ("sell", v)
+    for bmap in (1, 5, 7, 1000):                                # workgroups dealt over the matrix in other ways: same bits
+        sell.set_option("block_map", bmap)
+        for v in (0, 22):
+            sell.set_option("variant", v)
+            assert _mult(sell, x, rows).cpu().numpy().tobytes() == want.tobytes(), ("sell", v, "block_map", bmap)
+    sell.set_option("block_map", 0)
     for v in (4, 12):                                           # 16-byte loads: two partial sums per row
         sell.set_option("variant", v)
         _check_reassociated(orc, _mult(sell, x, rows), want, bound, ("sell", v))
@@ -143,6 +149,8 @@ def test_c2_stencil_252_against_the_oracle(orc):
     for v in (0, 11, 16, 22):
         scalar.set_option("variant", v)
         assert _mult(scalar, x, rows).cpu().numpy().tobytes() == want.tobytes(), ("csr_scalar", v)
+    scalar.set_option("block_map", 5)
+    assert _mult(scalar, x, rows).cpu().numpy().tobytes() == want.tobytes(), ("csr_scalar", 22, "block_map", 5)
     scalar.free()
 
     # ---- the reassociating CSR kernels, every variant that analyze may pick here
@@ -151,6 +159,9 @@ def test_c2_stencil_252_against_the_oracle(orc):
         for v in variants:
             m.set_option("variant", v)
             _check_reassociated(orc, _mult(m, x, rows), want, bound, (S.FORMAT_NAMES[fmt], v))
+        y0 = _mult(m, x, rows).clone()
+        m.set_option("block_map", 3)
+        assert torch.equal(_mult(m, x, rows), y0), (S.FORMAT_NAMES[fmt], "block_map", 3)
         m.free()
 
 

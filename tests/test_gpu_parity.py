@@ -688,3 +688,34 @@ def test_reassociating_kernels_meet_the_componentwise_bound(orc, g):
             m.set_option("variant", v)
             check(m, (name, v))
         m.free()
+
+
+def test_block_map_leaves_the_bits_alone(g):
+    """Option block_map only changes which workgroup takes which piece of the matrix: for every format, y under
+    block_map 1 (consecutive) and under runs of 2, 5, 64 workgroups per XCD equals y under block_map 0 bit for
+    bit (kernel variants of every family; grids smaller and larger than a round of 8 runs)."""
+    rows, cols = int(g["rows"]), int(g["cols"])
+    csr = (g["csr1_row_ptr"], g["csr1_col"], g["csr1_val"])
+    for dtype in (S.F64, S.F32):
+        xin = g["x"].astype(np.float32).astype(np.float64) if dtype == S.F32 else g["x"]
+        handles = [(Matrix.sell(rows, cols, *csr, dtype, 64, 1024), [0, 2, 12, 16, 22]),
+                   (Matrix.sellp(rows, cols, *csr, dtype, 64), [0, 4, 9, 18, 21]),
+                   (Matrix.sellp(rows, cols, *csr, dtype, 4), [0]),
+                   (Matrix.sell_dfc(rows, cols, *csr, dtype, 64, 1024), [0, 3, 5, 8]),
+                   (Matrix.csr(rows, cols, coo_of(g, "in"), 1, dtype, S.CSR_SCALAR), [0, 1, 3, 11]),
+                   (Matrix.csr(rows, cols, coo_of(g, "in"), 1, dtype, S.CSR_VECTOR), [None]),
+                   (Matrix.csr_merge(rows, cols, coo_of(g, "in"), dtype), [0, 1]),
+                   (Matrix.csr_bal(rows, cols, coo_of(g, "in"), dtype), [0, 1])]
+        for m, variants in handles:
+            for v in variants:
+                if v is not None:
+                    m.set_option("variant", v)
+                m.set_option("block_map", 0)
+                y0 = m.mult(xin)
+                for bmap in (1, 2, 5, 64):
+                    m.set_option("block_map", bmap)
+                    assert m.info.block_map == bmap
+                    assert bits_equal(y0, m.mult(xin)), (m.info.format, v, dtype, bmap)
+            with pytest.raises(S.SpmvHipError, match="block_map"):
+                m.set_option("block_map", -1)
+            m.free()

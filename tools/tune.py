@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--p0", default="0", help="comma list of p0 values (lanes / tile size / slice height)")
     ap.add_argument("--variants", default="0")
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--block-maps", default="", help="comma list of option block_map values to time every variant under (0, 1)")
     ap.add_argument("--hot", type=int, default=0, help="option hot_columns of CSR-based handles (0, 1, 2)")
     ap.add_argument("--hot-variants", default="", help="with --hot 2: comma list of tile kernels of the stacked matrix (0, 1, 3, 4)")
     args = ap.parse_args()
@@ -66,7 +67,10 @@ def main():
         variants = [v if v == "auto" else int(v) for v in args.variants.split(",")]
         if args.hot_variants:
             variants = [("hot", int(v)) for v in args.hot_variants.split(",")]
-        for var in variants:
+        maps = [int(v) for v in args.block_maps.split(",")] if args.block_maps else [None]
+        for var, bmap in [(v, b) for v in variants for b in maps]:
+            if bmap is not None:
+                m.set_option("block_map", bmap)
             if isinstance(var, tuple):
                 m.set_option("hot_variant", var[1])
                 var = 100 + var[1]
@@ -86,7 +90,7 @@ def main():
                 y0 = y.clone()
             err = float(torch.linalg.vector_norm(y - y0) / torch.linalg.vector_norm(y0))
             med = ms[len(ms) // 2]
-            print(f"p0={p0:6d} variant={var:3d}  median {med:8.4f} ms  min {ms[0]:8.4f} ms  "
+            print(f"p0={p0:6d} variant={var:3d}" + (f" map={bmap}" if bmap is not None else "") + f"  median {med:8.4f} ms  min {ms[0]:8.4f} ms  "
                   f"{b_alg / med / 1e6:8.1f} GB/s alg ({b_alg / med / 1e6 / 80:.1f}% of 8 TB/s)  "
                   f"{2 * nnz / med / 1e6:8.1f} GFLOP/s  stored {m.info.stored}  relerr-vs-first {err:.2e}", flush=True)
             info = m.info
