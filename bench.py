@@ -628,7 +628,7 @@ def main(argv=None):
             gv = min(trial, key=trial.get)
             m.set_option("variant", gv)
             other = {}
-            for bm in (0, 1, 3, 5, 7):        # and the fastest way of dealing the workgroups over the matrix
+            for bm in (0, 1, 2, 3, 4, 5, 8):        # and the fastest way of dealing the workgroups over the matrix
                 m.set_option("block_map", bm)
                 _, ms = timed_region(step, 5, 2)
                 other[bm] = ms[len(ms) // 2]

@@ -416,16 +416,17 @@ int spmv_hip_scale_dev(int n, const void *d_y, void *d_x, int dtype, const doubl
  *    the 128-byte line an L2 hit moves into the L1.  1, 3 and 4 give the same
  *    bits.
  *  "block_map" = which piece of the matrix a workgroup takes (spmv_hip_analyze
- *    picks it by trial after the kernel variant, from 0, 1, 3, 5, 7; the bits of
+ *    picks it by trial after the kernel variant, from 0, 1, 2, 3, 4, 5, 8; the bits of
  *    y do not depend on it).  The hardware deals consecutive workgroups over the
  *    8 XCDs in turn.  0 (default): every XCD walks one contiguous eighth of the
  *    matrix, so each private L2 sees its own window of x and every line of x
  *    leaves HBM once.  1: consecutive workgroups walk consecutive pieces, so all
  *    XCDs move through the matrix side by side.  K > 1 (up to 2^20): runs of K
  *    consecutive pieces per XCD, dealt in turn; x is then fetched by several L2s
- *    (27-point stencil 252^3: 4.19 GB moved instead of 3.90), but the eight
- *    streams no longer meet on the same memory channels -- SELL-64-1024 fp64 on
- *    that matrix 0.803 ms with 0, 0.794 with 1, 0.761 with 5.  The column-split
+ *    (27-point stencil 252^3: 4.19 GB moved instead of 3.90 with 1), but the
+ *    eight XCDs then work side by side in one region of the matrix and of y --
+ *    SELL-64-1024 fp64 on that matrix 0.803 ms with 0, 0.794 with 1, 0.761 with
+ *    5.  The column-split
  *    copy behind "hot_columns" = 2 always keeps 0 (an XCD has to stay with its
  *    column group).
  *  "exact_order" = 1: spmv_hip_analyze may only pick kernel variants that leave

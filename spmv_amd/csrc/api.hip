@@ -697,9 +697,10 @@ int spmv_hip_set_row_map(spmv_hip_matrix *m, const int *d_row_map)
 // only when the caller asks for the time).
 // Values of the option "block_map" a kernel trial compares: an eighth of the matrix per XCD, consecutive
 // workgroups on consecutive pieces, and short runs of workgroups per XCD -- odd run lengths keep the eight
-// XCDs' streams from meeting on the same memory channels (27-point stencil 252^3, SELL-64-1024, fp64:
-// 0.803 ms with 0, 0.794 with 1, 0.761 with 5).
-static const int kBlockMapCandidates[] = {0, 1, 3, 5, 7};
+// XCDs working side by side in one region of the matrix (27-point stencil 252^3, fp64: SELL-64-1024 0.803 ms
+// with 0, 0.794 with 1, 0.761 with 5; SELLP with every index read 0.946 / 0.921 / 0.909 with 0 / 1 / 4;
+// lane-per-row CSR 1.091 / 1.075 / 1.055 with 0 / 1 / 8).
+static const int kBlockMapCandidates[] = {0, 1, 2, 3, 4, 5, 8};
 
 static int analyze_impl(spmv_hip_matrix *m, int reps, float *best_ms_out)
 {

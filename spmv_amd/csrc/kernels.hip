@@ -1,10 +1,14 @@
 // SpMV kernels for gfx950 (MI355X): wave64, 256-thread workgroups, HBM-bound.
 //
-// Every kernel walks the matrix in storage order so that consecutive workgroup
-// ids stream consecutive HBM addresses; the workgroup id is first remapped so
-// that each XCD (workgroups are dealt round-robin over the 8 XCDs) owns one
-// contiguous eighth of the matrix and its private L2 keeps that eighth's window
-// of x instead of all eight L2s caching the same window.
+// Every kernel walks the matrix in storage order so that consecutive logical
+// blocks stream consecutive HBM addresses.  Which logical block a workgroup
+// takes is the handle's "block_map" (xcd_block, device_utils.h): the hardware
+// deals workgroups round-robin over the 8 XCDs, and the map gives each XCD
+// either one contiguous eighth of the matrix (its private L2 then keeps that
+// eighth's window of x instead of all eight L2s caching the same window) or
+// short runs of consecutive blocks in turn (all XCDs then work side by side in
+// one region of the matrix and of y, which the memory side likes better on
+// matrices whose window of x is small).  The kernel trial picks.
 //
 // Summation order per kernel (what the parity tolerance has to cover):
 //   csr_scalar, sliced (lane per row): ascending column position, one fma per
@@ -68,9 +72,9 @@ __global__ __launch_bounds__(kBlock) void csr_scalar_kernel(int rows, const int 
                                                             const int *__restrict__ col,
                                                             const T *__restrict__ val,
                                                             const int *__restrict__ row_map,
-                                                            const T *__restrict__ x, T *__restrict__ y, int plain)
+                                                            const T *__restrict__ x, T *__restrict__ y, int map)
 {
-    unsigned b = xcd_block(blockIdx.x, gridDim.x, plain);
+    unsigned b = xcd_block(blockIdx.x, gridDim.x, map);
     int row = (int)(b * kBlock + threadIdx.x);
     if (row >= rows) return;
     int beg = row_ptr[row], end = row_ptr[row + 1];
@@ -95,11 +99,11 @@ __global__ __launch_bounds__(kWave) void csr_rows_lds_kernel(int rows, const int
                                                              const int *__restrict__ col,
                                                              const T *__restrict__ val,
                                                              const int *__restrict__ row_map,
-                                                             const T *__restrict__ x, T *__restrict__ y, int plain)
+                                                             const T *__restrict__ x, T *__restrict__ y, int map)
 {
     constexpr int kCap = kWave * IPL;
     __shared__ xv_pair<T> stage[kCap];
-    const int blk = (int)xcd_block(blockIdx.x, gridDim.x, plain);
+    const int blk = (int)xcd_block(blockIdx.x, gridDim.x, map);
     const int lane = threadIdx.x;
     const int row = blk * kWave + lane;
     const int last = min(blk * kWave + kWave, rows);
@@ -169,12 +173,12 @@ __global__ __launch_bounds__(kWave) void csr_rows_lds_pat_kernel(int rows, const
                                                                  const T *__restrict__ val,
                                                                  const unsigned char *__restrict__ pattern_len,
                                                                  const int *__restrict__ row_map,
-                                                                 const T *__restrict__ x, T *__restrict__ y, int plain)
+                                                                 const T *__restrict__ x, T *__restrict__ y, int map)
 {
     constexpr int kCap = kWave * IPL;
     __shared__ xv_pair<T> stage[kCap];
     __shared__ int dist[32];
-    const int blk = (int)xcd_block(blockIdx.x, gridDim.x, plain);
+    const int blk = (int)xcd_block(blockIdx.x, gridDim.x, map);
     const int lane = threadIdx.x;
     const int row0 = blk * kWave;
     const int row = row0 + lane;
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(kBlock) void csr_vector_kernel(int rows, const int 
                                                             const int *__restrict__ col,
                                                             const T *__restrict__ val,
                                                             const int *__restrict__ row_map,
-                                                            const T *__restrict__ x, T *__restrict__ y, int plain)
+                                                            const T *__restrict__ x, T *__restrict__ y, int map)
 {
     static_assert(R <= G, "the first R lanes of a group store its R rows");
     constexpr int kRowsPerBlock = kBlock / G * R;
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(kBlock) void csr_vector_kernel(int rows, const int 
     const unsigned nblocks = (unsigned)((rows + kRowsPerBlock - 1) / kRowsPerBlock);
     const unsigned bid = blockIdx.y * gridDim.x + blockIdx.x;
     if (bid >= nblocks) return;
-    const unsigned b = xcd_block(bid, nblocks, plain);
+    const unsigned b = xcd_block(bid, nblocks, map);
     const int lane = threadIdx.x % G;
     const int row0 = (int)(b * kRowsPerBlock) + (int)(threadIdx.x / G) * R;
     int ptr[R + 1];
@@ -308,12 +312,12 @@ __global__ __launch_bounds__(kWave) void csr_vector_lds_kernel(int rows, const i
                                                                const T *__restrict__ val,
                                                                const unsigned char *__restrict__ pattern_len,
                                                                const int *__restrict__ row_map,
-                                                               const T *__restrict__ x, T *__restrict__ y, int plain)
+                                                               const T *__restrict__ x, T *__restrict__ y, int map)
 {
     constexpr int kCap = kWave * IPL, kRowsPerPass = kWave / G;
     __shared__ T prod[kCap];
     __shared__ int dist[32];
-    const int blk = (int)xcd_block(blockIdx.x, gridDim.x, plain);
+    const int blk = (int)xcd_block(blockIdx.x, gridDim.x, map);
     const int lane = threadIdx.x, sub = lane % G;
     const int row = blk * kWave + lane;
     const int last = min(blk * kWave + kWave, rows);
@@ -406,9 +410,9 @@ __global__ __launch_bounds__(kBlock) void sliced64_kernel(int rows, int nslices,
                                                           const int *__restrict__ row_order,
                                                           const int *__restrict__ scol,
                                                           const T *__restrict__ sval,
-                                                          const T *__restrict__ x, T *__restrict__ y, int plain)
+                                                          const T *__restrict__ x, T *__restrict__ y, int map)
 {
-    unsigned b = xcd_block(blockIdx.x, gridDim.x, plain);
+    unsigned b = xcd_block(blockIdx.x, gridDim.x, map);
     int s = __builtin_amdgcn_readfirstlane((int)(b * (kBlock / kWave) + threadIdx.x / kWave));
     if (s >= nslices) return;
     int lane = threadIdx.x & (kWave - 1);
@@ -453,14 +457,14 @@ __global__ __launch_bounds__(kBlock) void sliced64_wide_kernel(int rows, int nsl
                                                                const int *__restrict__ row_order,
                                                                     const int *__restrict__ scol,
                                                                const T *__restrict__ sval,
-                                                               const T *__restrict__ x, T *__restrict__ y, int plain)
+                                                               const T *__restrict__ x, T *__restrict__ y, int map)
 {
     constexpr int R = 16 / sizeof(T);        // rows per lane: 2 (fp64), 4 (fp32)
     constexpr int HL = kWave / R;            // lanes per column: 32, 16
     constexpr int P = R;                     // columns per wave instruction: 2, 4
     typedef T TV __attribute__((ext_vector_type(R)));
     typedef int IV __attribute__((ext_vector_type(R)));
-    unsigned b = xcd_block(blockIdx.x, gridDim.x, plain);
+    unsigned b = xcd_block(blockIdx.x, gridDim.x, map);
     int s = __builtin_amdgcn_readfirstlane((int)(b * (kBlock / kWave) + threadIdx.x / kWave));
     if (s >= nslices) return;
     const int lane = threadIdx.x & (kWave - 1);
@@ -542,9 +546,9 @@ __global__ __launch_bounds__(kBlock) void sliced64_diag_kernel(int rows, int col
                                                                const int *__restrict__ sdiag,
                                                                const int *__restrict__ scol,
                                                                const T *__restrict__ sval,
-                                                               const T *__restrict__ x, T *__restrict__ y, int plain)
+                                                               const T *__restrict__ x, T *__restrict__ y, int map)
 {
-    unsigned b = xcd_block(blockIdx.x, gridDim.x, plain);
+    unsigned b = xcd_block(blockIdx.x, gridDim.x, map);
     int s = __builtin_amdgcn_readfirstlane((int)(b * (kBlock / kWave) + threadIdx.x / kWave));
     if (s >= nslices) return;
     const int lane = threadIdx.x & (kWave - 1);
@@ -605,9 +609,9 @@ __global__ __launch_bounds__(kBlock) void sell_dfc_kernel(int rows, int nslices,
                                                           const T *__restrict__ sval,
                                                           const T *__restrict__ x, T *__restrict__ y,
                                                           const int64_t *__restrict__ vop_ptr = nullptr,
-                                                          const int *__restrict__ sdiag = nullptr, int plain = 0)
+                                                          const int *__restrict__ sdiag = nullptr, int map = 0)
 {
-    unsigned b = xcd_block(blockIdx.x, gridDim.x, plain);
+    unsigned b = xcd_block(blockIdx.x, gridDim.x, map);
     int s = __builtin_amdgcn_readfirstlane((int)(b * (kBlock / kWave) + threadIdx.x / kWave));
     if (s >= nslices) return;
     const int lane = threadIdx.x & (kWave - 1);
@@ -676,11 +680,11 @@ __global__ __launch_bounds__(kWave) void sell_dfc_lds_kernel(int rows, int nslic
                                                              const int *__restrict__ row_order,
                                                              const int *__restrict__ scol,
                                                              const T *__restrict__ sval,
-                                                             const T *__restrict__ x, T *__restrict__ y, int plain)
+                                                             const T *__restrict__ x, T *__restrict__ y, int map)
 {
     constexpr int kCap = kWave * IPL, U = 8;
     __shared__ xv_pair<T> stage[kCap];
-    const int s = (int)xcd_block(blockIdx.x, gridDim.x, plain);
+    const int s = (int)xcd_block(blockIdx.x, gridDim.x, map);
     const int lane = threadIdx.x;
     const int r = s * kWave + lane;
     const int len = r < rows ? sorted_len[r] : 0;
@@ -758,9 +762,9 @@ __global__ __launch_bounds__(kBlock) void sliced_any_kernel(int rows, int height
                                                             const int *__restrict__ row_order,
                                                             const int *__restrict__ scol,
                                                             const T *__restrict__ sval,
-                                                            const T *__restrict__ x, T *__restrict__ y, int plain)
+                                                            const T *__restrict__ x, T *__restrict__ y, int map)
 {
-    unsigned b = xcd_block(blockIdx.x, gridDim.x, plain);
+    unsigned b = xcd_block(blockIdx.x, gridDim.x, map);
     int r = (int)(b * kBlock + threadIdx.x);
     if (r >= rows) return;
     int s = r / height, k = r - s * height;
@@ -807,13 +811,13 @@ __global__ __launch_bounds__(kWave) void wave_tile_kernel(int list_len, const in
                                                           const int *__restrict__ col,
                                                           const T *__restrict__ val,
                                                           const T *__restrict__ x, T *__restrict__ y,
-                                                          int *__restrict__ row_carry, T *__restrict__ val_carry, int plain)
+                                                          int *__restrict__ row_carry, T *__restrict__ val_carry, int map)
 {
     constexpr int kCap = kWave * IPL;
     __shared__ T prod[kCap];
     __shared__ int rend[kCap];
     __shared__ int dist[32];
-    const int t = (int)xcd_block(blockIdx.x, gridDim.x, plain);
+    const int t = (int)xcd_block(blockIdx.x, gridDim.x, map);
     const int lane = threadIdx.x;
     const int a0 = tile_coord[2 * t], b0 = tile_coord[2 * t + 1];
     const int a1 = tile_coord[2 * t + 2], b1 = tile_coord[2 * t + 3];

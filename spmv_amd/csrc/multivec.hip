@@ -35,9 +35,9 @@ __global__ __launch_bounds__(kBlock) void sliced64_mv_kernel(int rows, int cols,
                                                              const int *__restrict__ scol,
                                                              const T *__restrict__ sval,
                                                              const T *__restrict__ x, int64_t ldx,
-                                                             T *__restrict__ y, int64_t ldy)
+                                                             T *__restrict__ y, int64_t ldy, int map)
 {
-    unsigned b = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    unsigned b = xcd_block(blockIdx.x, gridDim.x, map);
     int s = __builtin_amdgcn_readfirstlane((int)(b * (kBlock / kWave) + threadIdx.x / kWave));
     if (s >= nslices) return;
     const int lane = threadIdx.x & (kWave - 1);
@@ -103,9 +103,9 @@ __global__ __launch_bounds__(kBlock) void sliced_any_mv_kernel(int rows, int hei
                                                                const int *__restrict__ scol,
                                                                const T *__restrict__ sval,
                                                                const T *__restrict__ x, int64_t ldx,
-                                                               T *__restrict__ y, int64_t ldy)
+                                                               T *__restrict__ y, int64_t ldy, int map)
 {
-    unsigned b = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    unsigned b = xcd_block(blockIdx.x, gridDim.x, map);
     int r = (int)(b * kBlock + threadIdx.x);
     if (r >= rows) return;
     const int s = r / height, k0 = r - s * height;
@@ -137,9 +137,9 @@ __global__ __launch_bounds__(kBlock) void sell_dfc_mv_kernel(int rows, int nslic
                                                              const int *__restrict__ scol,
                                                              const T *__restrict__ sval,
                                                              const T *__restrict__ x, int64_t ldx,
-                                                             T *__restrict__ y, int64_t ldy)
+                                                             T *__restrict__ y, int64_t ldy, int map)
 {
-    unsigned b = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    unsigned b = xcd_block(blockIdx.x, gridDim.x, map);
     int s = __builtin_amdgcn_readfirstlane((int)(b * (kBlock / kWave) + threadIdx.x / kWave));
     if (s >= nslices) return;
     const int lane = threadIdx.x & (kWave - 1);
@@ -193,11 +193,11 @@ __global__ __launch_bounds__(kWave) void csr_rows_lds_mv_kernel(int rows, const 
                                                                 const unsigned char *__restrict__ pattern_len,
                                                                 const int *__restrict__ row_map,
                                                                 const T *__restrict__ x, int64_t ldx,
-                                                                T *__restrict__ y, int64_t ldy)
+                                                                T *__restrict__ y, int64_t ldy, int map)
 {
     constexpr int kCap = kWave * IPL;
     __shared__ mv_entry<T, NV> stage[kCap];
-    const int blk = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int blk = (int)xcd_block(blockIdx.x, gridDim.x, map);
     const int lane = threadIdx.x;
     const int row = blk * kWave + lane;
     const int last = min(blk * kWave + kWave, rows);
@@ -273,7 +273,7 @@ static int launch_block(const spmv_hip_matrix *m, const T *x, int64_t ldx, T *y,
     case SPMV_HIP_CSR_BAL:
         hipLaunchKernelGGL((csr_rows_lds_mv_kernel<T, 4, NV, NT>), dim3(blocks_for(m->rows, kWave)), dim3(kWave), 0, st,
                            m->rows, m->d_row_ptr, m->d_col, (const T *)m->d_val,
-                           m->format == SPMV_HIP_CSR_SCALAR ? m->d_block_pat : nullptr, m->d_row_map, x, ldx, y, ldy);
+                           m->format == SPMV_HIP_CSR_SCALAR ? m->d_block_pat : nullptr, m->d_row_map, x, ldx, y, ldy, m->block_map);
         break;
     case SPMV_HIP_SELL:
     case SPMV_HIP_SELLP:
@@ -287,26 +287,26 @@ static int launch_block(const spmv_hip_matrix *m, const T *x, int64_t ldx, T *y,
             if (perm)
                 hipLaunchKernelGGL((sliced64_mv_kernel<T, true, NV, U, NT>), grid, block, 0, st, m->rows, m->columns,
                                    m->nslices, m->d_slice_ptr, m->d_row_order, diag, m->d_scol, sv, x,
-                                   ldx, y, ldy);
+                                   ldx, y, ldy, m->block_map);
             else
                 hipLaunchKernelGGL((sliced64_mv_kernel<T, false, NV, U, NT>), grid, block, 0, st, m->rows, m->columns,
                                    m->nslices, m->d_slice_ptr, m->d_row_order, diag, m->d_scol, sv, x,
-                                   ldx, y, ldy);
+                                   ldx, y, ldy, m->block_map);
         } else {
             const dim3 grid(blocks_for(m->rows, kBlock)), block(kBlock);
             if (perm)
                 hipLaunchKernelGGL((sliced_any_mv_kernel<T, true, NV>), grid, block, 0, st, m->rows, m->slice_height,
-                                   m->d_slice_ptr, m->d_row_order, m->d_scol, sv, x, ldx, y, ldy);
+                                   m->d_slice_ptr, m->d_row_order, m->d_scol, sv, x, ldx, y, ldy, m->block_map);
             else
                 hipLaunchKernelGGL((sliced_any_mv_kernel<T, false, NV>), grid, block, 0, st, m->rows, m->slice_height,
-                                   m->d_slice_ptr, m->d_row_order, m->d_scol, sv, x, ldx, y, ldy);
+                                   m->d_slice_ptr, m->d_row_order, m->d_scol, sv, x, ldx, y, ldy, m->block_map);
         }
         break;
     }
     case SPMV_HIP_SELL_DFC:
         hipLaunchKernelGGL((sell_dfc_mv_kernel<T, NV, (NV >= 8 ? 2 : 4), NT>), dim3(blocks_for(m->nslices, kBlock / kWave)),
                            dim3(kBlock), 0, st, m->rows, m->nslices, m->d_slice_ptr, m->d_sorted_len, m->d_row_order,
-                           m->d_scol, (const T *)m->d_sval, x, ldx, y, ldy);
+                           m->d_scol, (const T *)m->d_sval, x, ldx, y, ldy, m->block_map);
         break;
     default: set_error("unknown format %d", m->format); return 1;
     }
