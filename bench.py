@@ -68,6 +68,8 @@ def parse_args(argv=None):
     ap.add_argument("--sigma", type=int, default=1024)
     ap.add_argument("--p0", type=int, default=0, help="format parameter (lanes per row / tile size / slice height)")
     ap.add_argument("--variant", type=int, default=-1, help="N = 1: this kernel variant instead of the one the trial picks")
+    ap.add_argument("--block-map", type=int, default=-1,
+                    help="N = 1, with --variant: option block_map (how workgroups are dealt over the matrix) instead of 0")
     ap.add_argument("--hot-columns", type=int, default=0, choices=[0, 1, 2],
                     help="N = 1, CSR-based formats: option hot_columns (1 columns relabeled by reference count, 2 dealt over the XCDs)")
     ap.add_argument("--hot-variant", type=int, default=-1, help="with --hot-columns 2: this tile kernel of the column-split copy")
@@ -571,7 +573,7 @@ def main(argv=None):
                    S.CSR_VECTOR: (5, 6), S.CSR_MERGE: (0, 1), S.CSR_BAL: (0, 1), S.SELL_DFC: tuple(range(0, 9))}
 
     def single_gpu_config(matrix, n, fmt_name, dtype_name, sigma=1024, p0_arg=0, variant=-1, hot=0, hot_variant=-1, steps=20,
-                          warmup=3, want_general=False, csr=None):
+                          warmup=3, want_general=False, csr=None, block_map=-1):
         """One configuration on this GPU, measured like the headline one.  fmt_name "auto": the format the
         library's trial picks (spmv_hip_create_auto_from_device_csr).  `csr`: a generated matrix to reuse."""
         dtype = S.F64 if dtype_name == "f64" else S.F32
@@ -595,6 +597,8 @@ def main(argv=None):
                 m.set_option("hot_columns", hot)
             if variant >= 0:
                 m.set_option("variant", variant)
+                if block_map >= 0:
+                    m.set_option("block_map", block_map)
                 if hot == 2 and hot_variant >= 0:
                     m.set_option("hot_variant", hot_variant)
             else:
@@ -680,7 +684,8 @@ def main(argv=None):
     if world == 1:
         # ---- the headline configuration (or the one the flags name) -----------------
         res = single_gpu_config(args.matrix, n, args.format, args.dtype, args.sigma, args.p0, args.variant, args.hot_columns,
-                                args.hot_variant, args.steps, args.warmup, want_general=not args.no_general)
+                                args.hot_variant, args.steps, args.warmup, want_general=not args.no_general,
+                                block_map=args.block_map)
         kernel_ms = res["kernel_ms"]
         mean_kernel_ms = sum(kernel_ms) / len(kernel_ms)
         ms_per_step = res["elapsed"] * 1e3 / args.steps

@@ -30,6 +30,10 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 STEPS, WARMUP = 10, 3
+# what the kernel trial chooses from on the headline matrix: the 27-column batch of the index-skipping kernel with and
+# without non-temporal loads, the widest 16-byte-load kernels likewise; every block_map the trial compares
+SWEEP_SELL_VARIANTS = "18,22,21,4,12"
+SWEEP_MAPS = "0,1,2,3,4,5,8"
 SHORT = (("wave_tile", "tile"), ("tile_fixup", "fixup"), ("permute_x", "permute_x"), ("sum_partials", "sum_partials"))
 PRODUCT_KERNELS = re.compile(r"spmv::(sliced|csr_|wave_tile|tile_fixup|permute_x|sum_partials|sell_dfc)")
 
@@ -55,6 +59,25 @@ def counter_per_product(directory, counter, products):
     return {k: v / products for k, v in total.items()}
 
 
+def counter_by_setting(directory, counter, manifest):
+    """Per setting of a tools/traffic_sweep.py run: the counter summed over the product kernels of one product.
+    The product kernels' dispatches, in dispatch order, split evenly over the settings of the manifest."""
+    rows = []
+    for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if row["Counter_Name"] == counter and PRODUCT_KERNELS.search(row["Kernel_Name"]):
+                    order = row.get("Dispatch_Id") or row.get("Start_Timestamp") or row.get("Correlation_Id")
+                    rows.append((int(order), float(row["Counter_Value"])))
+    rows.sort()
+    n = len(manifest["order"])
+    if not rows or len(rows) % (n * manifest["launches"]):
+        raise SystemExit(f"{len(rows)} product-kernel dispatches under {directory} do not split over {n} settings x "
+                         f"{manifest['launches']} products")
+    per = len(rows) // n
+    return [sum(v for _, v in rows[i * per:(i + 1) * per]) / manifest["launches"] for i in range(n)]
+
+
 def duration_per_product(directory, products):
     total = collections.defaultdict(float)
     for path in glob.glob(os.path.join(directory, "**", "*kernel_trace.csv"), recursive=True):
@@ -77,13 +100,18 @@ def configurations(line):
     out = []
     main_flags = ["--no-general", "--no-other-configs", "--no-cpu-baseline"]
     r = line["roofline"]
-    out.append((f"sell/stencil27/252/f64/gpus1/variant{r['kernel_variant']}", ["--variant", str(r["kernel_variant"])] + main_flags, False))
+    def with_map(v, k):
+        return f"variant{v}" + (f"+map{k}" if k else "")
+    k = line["config"].get("block_map", 0)
+    out.append((f"sell/stencil27/252/f64/gpus1/{with_map(r['kernel_variant'], k)}",
+                ["--variant", str(r["kernel_variant"]), "--block-map", str(k)] + main_flags, False))
     if "general" in r:
-        g = r["general"]["kernel_variant"]
-        out.append((f"sell/stencil27/252/f64/gpus1/variant{g}", ["--variant", str(g)] + main_flags, False))
+        g, k = r["general"]["kernel_variant"], r["general"].get("block_map", 0)
+        out.append((f"sell/stencil27/252/f64/gpus1/{with_map(g, k)}", ["--variant", str(g), "--block-map", str(k)] + main_flags, False))
     for o in line.get("other_configs", []):
         matrix, size = ("laplacian2d", "1000") if o["workload"].startswith("laplacian2d") else ("rmat", o["workload"].split()[2])
-        flags = ["--matrix", matrix, "--size", size, "--format", o["format"], "--variant", str(o["kernel_variant"])] + main_flags
+        flags = ["--matrix", matrix, "--size", size, "--format", o["format"], "--variant", str(o["kernel_variant"]),
+                 "--block-map", str(o.get("block_map", 0))] + main_flags
         if o["format"] == "csr_vector":
             flags += ["--p0", str(o["lanes_per_row"])]
         if o["hot_columns"]:
@@ -140,6 +168,35 @@ def main():
             json.dump(table, f, indent=1, sort_keys=True)
             f.write("\n")
         print(f"{key}: {entry['bytes'] / 1e9:.3f} GB per product", flush=True)
+    # 2b. the kernel trial of a later run may settle on a neighbouring setting (the non-temporal twin of a variant,
+    # another block_map): the traffic of every setting it chooses from, measured in one process per counter
+    sweeps = [("stencil27", 252, "sell", SWEEP_SELL_VARIANTS)]
+    rmat = [o for o in line.get("other_configs", []) if o["workload"].startswith("rmat") and not o["hot_columns"]]
+    if rmat:
+        sweeps.append(("rmat", int(rmat[0]["workload"].split()[2]), rmat[0]["format"], "0,1"))
+    for matrix, size, fmt, variants in sweeps:
+        per, manifest = {}, None
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d, mf = os.path.join(out, f"sweep_{matrix}_{counter}"), os.path.join(out, f"sweep_{matrix}_{counter}.json")
+            run(["rocprofv3", "--pmc", counter, "--kernel-include-regex", "spmv::", "-f", "csv", "-d", d, "-o", "p", "--", py,
+                 os.path.join(ROOT, "tools", "traffic_sweep.py"), "--matrix", matrix, "--size", str(size), "--format", fmt,
+                 "--variants", variants, "--maps", SWEEP_MAPS, "--manifest", mf], os.path.join(out, f"sweep_{matrix}_{counter}.log"), 600)
+            manifest = json.load(open(mf))
+            per[counter] = counter_by_setting(d, counter, manifest)
+            shutil.rmtree(d, ignore_errors=True)
+        for i, (v, k) in enumerate(manifest["order"]):
+            read_b, write_b = per["FETCH_SIZE"][i] * 1024 * 2, per["WRITE_SIZE"][i] * 1024
+            key = f"{fmt}/{matrix}/{size}/f64/gpus1/variant{v}" + (f"+map{k}" if k else "")
+            if key in table and table[key].get("kernel_sources_sha256") == bench.kernel_source_hash() and "kernels" in table[key]:
+                continue
+            table[key] = {"bytes": int(read_b + write_b), "read_bytes": int(read_b), "write_bytes": int(write_b),
+                          "products": manifest["launches"], "kernel_sources_sha256": bench.kernel_source_hash(),
+                          "source": f"tools/profile_bench.py {tag} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                    f"tools/traffic_sweep.py: {manifest['launches']} products per setting, split by dispatch order)"}
+        with open(table_path, "w") as f:
+            json.dump(table, f, indent=1, sort_keys=True)
+            f.write("\n")
+        print(f"sweep {matrix} {fmt}: {len(manifest['order'])} settings recorded", flush=True)
     # 3. the line a plain run prints now
     with open(os.path.join(out, "bench_final.json"), "w") as f:
         p = subprocess.run([py, script], stdout=f, stderr=open(os.path.join(out, "bench_final.err"), "w"), timeout=600)
