@@ -116,6 +116,8 @@ def run_matrix(name: str, scale: float, formats, dtypes, min_iters: int, min_sec
                 variant = m.info.lanes_per_row * 256 + m.info.variant if fmt == S.CSR_VECTOR else m.info.variant
                 if mode == "auto":
                     variant = f"{S.FORMAT_NAMES[fmt]}:{variant}" + ("", "+hot", "+xcd")[m.info.hot_columns]
+                    if m.info.block_map and m.info.hot_columns != 2:
+                        variant += f"+map{m.info.block_map}"
                 m.free()
             except S.SpmvHipError as e:
                 lines.append(f"{mode};{name};{rows};{cols};{nnz};0;0;0;0;{'f64' if dtype == S.F64 else 'f32'};-1;0;nan;"

@@ -24,6 +24,7 @@ import tempfile
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 TUNE = os.path.join(ROOT, "tools", "tune.py")
 WARMUP = 3      # untimed products tune.py runs before the timed ones
+BLOCK_MAPS = "0,1,2,3,4,5,8"   # what spmv_hip_analyze compares (option block_map)
 
 
 def tune(extra, steps, profiler=None, timeout=400, every=False):
@@ -87,11 +88,13 @@ def main():
                     if fmt == "csr_vector":                       # the LDS-staged kernel at 2, 4, 8 lanes per row
                         trial += ["--p0", "2,4,8"]
                     best = min(tune(trial, 8, every=True), key=lambda r: r["median_ms"])
-                    first = tune(base + ["--variants", str(best["variant"])] +
-                                 (["--p0", str(best["lanes_per_row"])] if fmt == "csr_vector" else []), args.steps)
+                    pinned = base + ["--variants", str(best["variant"])] + (["--p0", str(best["lanes_per_row"])] if fmt == "csr_vector" else [])
+                    # then the way of dealing the workgroups over the matrix, as the library's trial does
+                    best = min(tune(pinned + ["--block-maps", BLOCK_MAPS], 8, every=True), key=lambda r: r["median_ms"])
+                    first = tune(pinned + ["--block-maps", str(best["block_map"])], args.steps)
                 else:
                     first = tune(base + ["--variants", "auto"], args.steps)
-                fixed = base + ["--variants", str(first["variant"])]
+                fixed = base + ["--variants", str(first["variant"]), "--block-maps", str(first.get("block_map", 0))]
                 if fmt == "csr_vector":
                     fixed += ["--p0", str(first["lanes_per_row"])]
                 if name.endswith("+xcd"):                         # the tile kernel of the column-split copy, as the trial chose it
@@ -108,6 +111,8 @@ def main():
                 variant = f"{first['lanes_per_row']} lanes, {first['variant']}" if fmt == "csr_vector" else str(first["variant"])
                 if name.endswith("+xcd"):
                     variant += f", tiles {first.get('hot_variant', 0)}"
+                elif first.get("block_map", 0):
+                    variant += f", block_map {first['block_map']}"
                 lines.append(f"| {name} | {dname} | {variant} | {ms:.3f} | {2 * nnz / ms / 1e6:.0f} | {b_alg / ms / 1e6:.0f} | "
                              f"{b_alg / ms / 1e6 / 80:.1f} | {bytes_moved / 1e9:.3f} | {bytes_moved / b_alg:.2f} | {bytes_moved / ms / 1e6:.0f} | "
                              f"{bytes_moved / ms / 1e6 / 80:.1f} | {first['stored'] / max(nnz, 1):.3f} |")

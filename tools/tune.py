@@ -95,7 +95,7 @@ def main():
                   f"{2 * nnz / med / 1e6:8.1f} GFLOP/s  stored {m.info.stored}  relerr-vs-first {err:.2e}", flush=True)
             info = m.info
             print("RESULT " + json.dumps({"format": args.format, "matrix": args.matrix, "n": args.n, "dtype": args.dtype,
-                                          "hot": args.hot, "hot_variant": info.hot_variant, "variant": info.variant, "lanes_per_row": info.lanes_per_row,
+                                          "hot": args.hot, "hot_variant": info.hot_variant, "variant": info.variant, "block_map": info.block_map, "lanes_per_row": info.lanes_per_row,
                                           "median_ms": med, "min_ms": ms[0], "rows": rows, "cols": cols, "nnz": nnz,
                                           "stored": info.stored, "b_alg": b_alg}), flush=True)
         m.free()
