@@ -161,3 +161,24 @@ def test_rccl_collectives_of_the_row_block_product_run_on_this_gpu():
     p.join(timeout=60)
     assert p.exitcode == 0
     assert gathered and p2p and sumsq == float(sum(i * i for i in range(1000)))
+
+
+def test_bench_eight_ranks_uneven_slabs_and_the_one_process_leg():
+    """`python bench.py --gpus 8` end to end on this box's one GPU (gloo): 67 planes over 8 ranks = slabs of 8 or 9
+    planes (the 66 / 67 shape of 530 planes over 8 GPUs), ranks with one neighbour and ranks with two; then the same
+    slabs as 8 blocks of one process through spmv_hip_dist_*, whose product of x_i = i must be exactly 0.0 on
+    every row away from the grid's faces."""
+    import json
+    p = _run_bench({"SPMV_BENCH_BACKEND": "gloo"}, "--gpus", "8", "--size", "48", "--total-planes", "67", "--steps", "3",
+                   "--warmup", "1")
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+    assert rec["n_gpus"] == 8 and rec["scaling"] == "strong" and rec["value"] > 0
+    assert rec["config"]["rows"] == 48 * 48 * 67 and rec["config"]["nnz"] == (3 * 48 - 2) ** 2 * (3 * 67 - 2)
+    assert rec["rccl"]["world"] == 8 and rec["rccl"]["ranks_seen"] == 8
+    assert rec["communication"]["halo_entries_rank0"] == 48 * 48
+    one = rec["c_abi_one_process"]
+    assert "error" not in one, one
+    assert one["blocks"] == 8 and one["nnz"] == rec["config"]["nnz"]
+    assert one["halo_per_block"] == [48 * 48] + [2 * 48 * 48] * 6 + [48 * 48]
+    assert one["halo_check"]["ok"] and one["halo_check"]["rows_wrong"] == 0
