@@ -183,7 +183,8 @@ spmv_hip_matrix *spmv_hip_create_from_device_csr(int format, int rows, int colum
  * driver_spmv.c:186-261) and tunes only inside SELL-C-sigma
  * (sellcs_analyze_matrix, sellcs_analyzer.c:46-120).  These creators extend
  * that trial to the formats themselves: merge-path CSR, lane-per-row CSR,
- * vector CSR, SELLP and SELL-64-1024 are each built from the same CSR (the
+ * vector CSR, SELLP, SELL-64-1024 and SELL-64-16384 (the window of sell.c:5)
+ * are each built from the same CSR (the
  * sliced ones only if they store at most 2x the non-zeros), tuned as by
  * spmv_hip_analyze with `reps` timed products per kernel variant, and the
  * fastest handle is returned (spmv_hip_get_info tells which).  create_auto

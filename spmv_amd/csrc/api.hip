@@ -802,11 +802,15 @@ int spmv_hip_analyze(spmv_hip_matrix *m, int reps)
 
 // Candidate formats of the automatic choice, in build order.  The sliced layouts are skipped when they
 // would store more than kAutoMaxPadding times the non-zeros.
-static const int kAutoFormats[] = {SPMV_HIP_CSR_MERGE, SPMV_HIP_CSR_SCALAR, SPMV_HIP_CSR_VECTOR, SPMV_HIP_SELLP, SPMV_HIP_SELL};
+// SELL-C-sigma is tried with windows of 1024 rows (results stay near their rows) and with the reference's own
+// default of 16384 (sell.c:5: less padding where row lengths vary a lot -- FEM stand-in HV15R 0.704 -> 0.664 ms).
+struct auto_candidate { int format; int64_t sigma; };
+static const auto_candidate kAutoFormats[] = {{SPMV_HIP_CSR_MERGE, 0}, {SPMV_HIP_CSR_SCALAR, 0}, {SPMV_HIP_CSR_VECTOR, 0},
+                                              {SPMV_HIP_SELLP, 0},     {SPMV_HIP_SELL, 1024},  {SPMV_HIP_SELL, 16384}};
 constexpr double kAutoMaxPadding = 2.0;
 constexpr int64_t kHotColumnsMinBytes = (int64_t)4 << 20;   // the L2 of one XCD
 
-static spmv_hip_matrix *view_of_device_csr(int format, int rows, int columns, int64_t nnz, const int *d_row_ptr,
+static spmv_hip_matrix *view_of_device_csr(int format, int64_t sigma, int rows, int columns, int64_t nnz, const int *d_row_ptr,
                                            const int *d_col, const void *d_val, int dtype, hipStream_t st)
 {
     spmv_hip_matrix *m = new_handle(format, dtype, rows, columns, nnz);
@@ -817,7 +821,7 @@ static spmv_hip_matrix *view_of_device_csr(int format, int rows, int columns, in
     m->d_col = const_cast<int *>(d_col);
     m->d_val = const_cast<void *>(d_val);
     m->max_padding = kAutoMaxPadding;
-    const int64_t p0 = format == SPMV_HIP_SELL ? kDefaultC : 0, p1 = format == SPMV_HIP_SELL ? 1024 : 0;
+    const int64_t p0 = format == SPMV_HIP_SELL ? kDefaultC : 0, p1 = format == SPMV_HIP_SELL ? sigma : 0;
     if (finish_from_device_csr(m, p0, p1, dtype == SPMV_HIP_F64, st)) {
         spmv_hip_free(m);
         return nullptr;
@@ -831,8 +835,9 @@ static spmv_hip_matrix *auto_from_device_csr(int rows, int columns, int64_t nnz,
 {
     spmv_hip_matrix *best = nullptr;
     float best_ms = 0;
-    for (int format : kAutoFormats) {
-        spmv_hip_matrix *m = view_of_device_csr(format, rows, columns, nnz, d_row_ptr, d_col, d_val, dtype, st);
+    for (const auto_candidate &c : kAutoFormats) {
+        if (c.format == SPMV_HIP_SELL && c.sigma > 1024 && rows <= 2048) continue;      // one window either way
+        spmv_hip_matrix *m = view_of_device_csr(c.format, c.sigma, rows, columns, nnz, d_row_ptr, d_col, d_val, dtype, st);
         if (!m) continue;                                    // e.g. too much padding: not a candidate
         float ms = 0;
         if (analyze_impl(m, reps, &ms)) { spmv_hip_free(m); continue; }

@@ -419,6 +419,8 @@ def test_auto_format_choice(orc, g, dtype):
     assert info.format in AUTO_FORMATS and info.nnz == nnz and info.dtype == dtype
     if info.format in (S.SELL, S.SELLP):
         assert info.stored <= 2 * max(nnz, 1)
+    if info.format == S.SELL:
+        assert info.sigma in (1024, 16384) and info.slice_height == 64      # the two windows the choice builds
     assert rel(orc, m.mult(xin), want) <= tol
     m.free()
     # the same choice over CSR arrays that stay in HBM
