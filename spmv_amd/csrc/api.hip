@@ -692,16 +692,16 @@ int spmv_hip_set_row_map(spmv_hip_matrix *m, const int *d_row_map)
     return 0;
 }
 
-// Times every kernel variant of the handle `reps` times and keeps the fastest; *best_ms_out (optional)
-// receives the summed time of the winner's `reps` launches (handles with a single variant are timed
-// only when the caller asks for the time).
-// Values of the option "block_map" a kernel trial compares: an eighth of the matrix per XCD, consecutive
-// workgroups on consecutive pieces, and short runs of workgroups per XCD -- odd run lengths keep the eight
-// XCDs working side by side in one region of the matrix (27-point stencil 252^3, fp64: SELL-64-1024 0.803 ms
-// with 0, 0.794 with 1, 0.761 with 5; SELLP with every index read 0.946 / 0.921 / 0.909 with 0 / 1 / 4;
-// lane-per-row CSR 1.091 / 1.075 / 1.055 with 0 / 1 / 8).
+// Values of the option "block_map" a kernel trial compares: an eighth of the matrix per XCD (0), consecutive
+// workgroups on consecutive pieces (1), and short runs of workgroups per XCD -- all XCDs then work side by side in
+// one region of the matrix and of y (27-point stencil 252^3, fp64: SELL-64-1024 0.803 ms with 0, 0.794 with 1,
+// 0.761 with 5; SELLP with every index read 0.946 / 0.921 / 0.909 with 0 / 1 / 4; lane-per-row CSR 1.091 / 1.075 /
+// 1.055 with 0 / 1 / 8).
 static const int kBlockMapCandidates[] = {0, 1, 2, 3, 4, 5, 8};
 
+// Times every kernel variant of the handle `reps` times and keeps the fastest, then the ways of dealing the
+// workgroups over the matrix likewise; *best_ms_out (optional) receives the summed time of the winner's `reps`
+// launches (handles with a single variant are timed only when the caller asks for the time).
 static int analyze_impl(spmv_hip_matrix *m, int reps, float *best_ms_out)
 {
     if (best_ms_out) *best_ms_out = 0;
