@@ -412,7 +412,7 @@ int spmv_hip_scale_dev(int n, const void *d_y, void *d_x, int dtype, const doubl
  *  "hot_variant" = tile kernel of that second copy (needs "hot_columns" = 2;
  *    spmv_hip_analyze picks it by trial): 0, 1 = the balanced-CSR kernels, one
  *    workgroup per tile; 3, 4 = persistent workgroups of 8 / 16 waves, one per
- *    CU, that keep the first 14336 / 8192 labels (fp64; fp32: 32768 / 24576)
+ *    CU, that keep the first 15360 / 10240 labels (fp64; fp32: 34816 / 28672)
  *    of their column group's share of x in LDS -- a gather served there saves
  *    the 128-byte line an L2 hit moves into the L1.  1, 3 and 4 give the same
  *    bits.

@@ -975,7 +975,7 @@ __device__ __forceinline__ void wave_lds_fence()
 
 template <typename T, int IPL, int W> struct hot_tile_shape {
     static constexpr int kCap = kWave * IPL;
-    static constexpr int kStageBytes = W * kCap * (int)(sizeof(T) + sizeof(int));
+    static constexpr int kStageBytes = W * kCap * (int)(sizeof(T) + sizeof(unsigned short));   // products + row ends (<= kCap: 16 bits)
     static constexpr int kHot = (160 * 1024 - kStageBytes) / (int)sizeof(T);      // all of the CU's LDS
 };
 
@@ -995,7 +995,7 @@ __global__ __launch_bounds__(kWave * W) void wave_tile_hot_kernel(const int *__r
     constexpr int kHot = shape::kHot;
     __shared__ T hot[kHot];
     __shared__ T prod_of_wave[W][kCap];
-    __shared__ int rend_of_wave[W][kCap];
+    __shared__ unsigned short rend_of_wave[W][kCap];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const int g = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
     const int hot_base = g * cpx;
@@ -1003,7 +1003,7 @@ __global__ __launch_bounds__(kWave * W) void wave_tile_hot_kernel(const int *__r
     for (int i = threadIdx.x; i < nhot; i += kWave * W) hot[i] = x[hot_base + i];
     __syncthreads();
     T *prod = prod_of_wave[wave];
-    int *rend = rend_of_wave[wave];
+    unsigned short *rend = rend_of_wave[wave];
     const int t_begin = groups.first_tile[g] + slot * W + wave, t_end = groups.first_tile[g + 1];
     const int stride = slots * W;
     constexpr int kLoads = IPL + 1;
@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(kWave * W) void wave_tile_hot_kernel(const int *__r
 #pragma unroll
         for (int i = 0; i < IPL; i++) {
             const int k = lane + i * kWave;
-            if (k < nr) rend[k] = row_end_list[a0 + k] - b0;
+            if (k < nr) rend[k] = (unsigned short)(row_end_list[a0 + k] - b0);
         }
         wave_lds_fence();
         for (int base = 0; base <= nr; base += kWave) {

@@ -522,8 +522,8 @@ int build_xcd_columns(const spmv_hip_matrix *m, bool val_is_f64, hipStream_t st,
     if ((int64_t)rows * kXcds > 0x7fffffffLL - 1) { set_error("hot_columns 2: %d rows x 8 exceed 32-bit row numbers", rows); return 1; }
     const int cpx = (int)(((int64_t)cols + 16 * kXcds - 1) / (16 * kXcds)) * 16;
     const size_t c = (size_t)cols, vrows = (size_t)rows * kXcds, labels = (size_t)cpx * kXcds;
-    // ranks dealt one at a time: 8192 per group (what a CU's LDS holds beside 16 waves of tile staging), whole lines
-    const int snake = std::min(65536, cols / (16 * kXcds) * (16 * kXcds));
+    // ranks dealt one at a time: 10240 per group (what a CU's LDS holds beside 16 waves of tile staging), whole lines
+    const int snake = std::min(81920, cols / (16 * kXcds) * (16 * kXcds));
     unsigned *d_count[2] = {nullptr, nullptr};
     int *d_id = nullptr, *d_rank_old = nullptr, *d_label_of_old = nullptr, *d_cnt = nullptr;
     int *d_huge = nullptr, *d_meta = nullptr, *d_seg_cnt = nullptr;
