@@ -433,7 +433,7 @@ int spmv_hip_scale_dev(int n, const void *d_y, void *d_x, int dtype, const doubl
  *  "exact_order" = 1: spmv_hip_analyze may only pick kernel variants that leave
  *    the bits of y as they are under the current setting, so that tuning noise
  *    cannot change results from run to run: for the sliced formats the variants
- *    that keep mult_csr_base's summation order (0, 16..23; a handle currently
+ *    that keep mult_csr_base's summation order (0, 16..31; a handle currently
  *    on a reassociating variant 1..12 is put back on 0), for vector CSR the
  *    current lanes per row and kernel family, for merge-path and balanced tiles
  *    variant 0 or variants 1 and 2 (they differ where a tile lies inside one
@@ -442,14 +442,17 @@ int spmv_hip_scale_dev(int n, const void *d_y, void *d_x, int dtype, const doubl
 int spmv_hip_set_option(spmv_hip_matrix *m, const char *name, int64_t value);
 /* sellcs_analyze_matrix (sell.c:30, sellcs_analyzer.c:46-120) re-thought for the
  * GPU: times every kernel variant of the handle's format `reps` times on a
- * zero vector and keeps the fastest.  Variants 0 and 16..23 of the sliced
+ * zero vector and keeps the fastest.  Variants 0 and 16..31 of the sliced
  * formats keep mult_csr_base's summation order (bit-identical y); 1..12 (16-byte
- * loads) reassociate.  All CSR_SCALAR variants (LDS chunk sizes) give the same
+ * loads, two / four partial sums per row) reassociate.  24..27 (fp64) are 16-byte
+ * loads in the exact order: a v_permlane32_swap hands each row's entries back to
+ * one lane (27-point stencil 252^3, SELLP with every index read: 1.02 -> 0.92 ms,
+ * same bits).  All CSR_SCALAR variants (LDS chunk sizes) give the same
  * bits.  For CSR_VECTOR the trial covers lanes per row x rows walked side by
  * side per lane group, and the LDS-staged kernel for short rows (variants 5..8).
  * Where the matrix has regular structure the trial includes the variants that
  * do not read column indices they can compute -- slice columns at one distance
- * from the diagonal (sliced formats 16..23, padding-free SELL 9..12), blocks of 64 rows or whole tiles
+ * from the diagonal (sliced formats 16..23 and, with 16-byte value loads, fp64 28..31; padding-free SELL 9..12), blocks of 64 rows or whole tiles
  * that repeat one row pattern (CSR_SCALAR 16..22, CSR_VECTOR 7..8, merge-path
  * and balanced tiles 2); each gives the bits of its index-reading twin. */
 int spmv_hip_analyze(spmv_hip_matrix *m, int reps);

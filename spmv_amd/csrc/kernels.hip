@@ -527,6 +527,179 @@ __global__ __launch_bounds__(kBlock) void sliced64_wide_kernel(int rows, int nsl
     if (r < rows) y[out_row] = mine;
 }
 
+// sliced64_wide_exact_kernel (fp64): the 16-byte loads of sliced64_wide_kernel with the summation order of
+// sliced64_kernel.  Lane (h, q) loads the rows 2q, 2q+1 of column 2jj + h; one v_permlane32_swap per 32-bit
+// half then trades the upper half-wave's row-2q entry against the lower half-wave's row-(2q+1) entry, after
+// which lane q < 32 holds row 2q's entries of columns 2jj and 2jj + 1 and lane 32 + q those of row 2q + 1.
+// Every lane then adds its one row's entries in ascending column order, one fma each: the order and operands of
+// mult_csr_base (csr.c:4-13), so y is bit-identical to it -- at the memory shape of the wide kernel.
+__device__ __forceinline__ void swap_half_waves(double &a, double &b)
+{
+    // a's lanes 32..63 <-> b's lanes 0..31
+    const long long ab = __builtin_bit_cast(long long, a), bb = __builtin_bit_cast(long long, b);
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)(ab & 0xFFFFFFFFll), (unsigned)(bb & 0xFFFFFFFFll), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(ab >> 32), (unsigned)(bb >> 32), false, false);
+    a = __builtin_bit_cast(double, ((long long)hi[0] << 32) | (long long)lo[0]);
+    b = __builtin_bit_cast(double, ((long long)hi[1] << 32) | (long long)lo[1]);
+}
+
+template <bool PERM, int U, bool NT>
+__global__ __launch_bounds__(kBlock) void sliced64_wide_exact_kernel(int rows, int nslices,
+                                                                     const int64_t *__restrict__ slice_ptr,
+                                                                     const int *__restrict__ row_order,
+                                                                     const int *__restrict__ scol,
+                                                                     const double *__restrict__ sval,
+                                                                     const double *__restrict__ x, double *__restrict__ y,
+                                                                     int map)
+{
+    typedef double TV __attribute__((ext_vector_type(2)));
+    typedef int IV __attribute__((ext_vector_type(2)));
+    constexpr int HL = kWave / 2;
+    unsigned b = xcd_block(blockIdx.x, gridDim.x, map);
+    int s = __builtin_amdgcn_readfirstlane((int)(b * (kBlock / kWave) + threadIdx.x / kWave));
+    if (s >= nslices) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int h = lane / HL, q = lane % HL;
+    // the row this lane sums after the trade: 2q (lower half-wave) or 2q + 1 (upper)
+    const int r = s * kWave + 2 * q + h;
+    const int out_row = PERM ? row_order[min(r, rows - 1)] : r;
+    const int64_t base = slice_ptr[s];
+    const int width = (int)((slice_ptr[s + 1] - base) >> 6);
+    const double *v = sval + base + q * 2;
+    const int *c = scol + base + q * 2;
+    double acc = 0;
+    const int steps = (width + 1) / 2;
+    for (int jj = 0; jj < steps; jj += U) {
+        IV cc[U];
+        TV vv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const IV *p = (const IV *)(c + (int64_t)min(2 * (jj + u) + h, width - 1) * kWave);
+            cc[u] = NT ? __builtin_nontemporal_load(p) : *p;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const TV *p = (const TV *)(v + (int64_t)min(2 * (jj + u) + h, width - 1) * kWave);
+            vv[u] = NT ? __builtin_nontemporal_load(p) : *p;
+        }
+        TV xx[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            xx[u][0] = x[cc[u][0]];
+            xx[u][1] = x[cc[u][1]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            double x0 = xx[u][0], x1 = xx[u][1], v0 = vv[u][0], v1 = vv[u][1];
+            swap_half_waves(x0, x1);
+            swap_half_waves(v0, v1);
+            // now (x0, v0) is this lane's row at column 2 (jj + u), (x1, v1) at the column after it
+            const int col = 2 * (jj + u);
+            if (col < width) acc = fma_t(x0, v0, acc);
+            if (col + 1 < width) acc = fma_t(x1, v1, acc);
+        }
+    }
+    if (r < rows) y[out_row] = acc;
+}
+
+// sliced64_diag_wide_kernel (fp64): sliced64_diag_kernel with the memory shape of sliced64_wide_exact_kernel.  Lane
+// (h, q) loads the values of rows 2q, 2q+1 of column 2jj + h with one 16-byte load; a column with a descriptor
+// takes its x operands from x[row + d] (its 64 indices stay unread), any other column reads its two indices; the
+// half-wave swap then hands each row's entries of columns 2jj, 2jj + 1 to one lane, which adds them in ascending
+// column order.  Same operands and order as sliced64_diag_kernel (padding lanes of described columns take x[0]),
+// so the same bits.
+template <bool PERM, int U, bool NT>
+__global__ __launch_bounds__(kBlock) void sliced64_diag_wide_kernel(int rows, int cols, int nslices,
+                                                                    const int64_t *__restrict__ slice_ptr,
+                                                                    const int *__restrict__ row_order,
+                                                                    const int *__restrict__ sdiag,
+                                                                    const int *__restrict__ scol,
+                                                                    const double *__restrict__ sval,
+                                                                    const double *__restrict__ x, double *__restrict__ y,
+                                                                    int map)
+{
+    typedef double TV __attribute__((ext_vector_type(2)));
+    typedef int IV __attribute__((ext_vector_type(2)));
+    constexpr int HL = kWave / 2;
+    unsigned b = xcd_block(blockIdx.x, gridDim.x, map);
+    int s = __builtin_amdgcn_readfirstlane((int)(b * (kBlock / kWave) + threadIdx.x / kWave));
+    if (s >= nslices) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int h = lane / HL, q = lane % HL;
+    // the two rows whose entries this lane loads, and the one it sums after the trade (2q + h)
+    const int ra = s * kWave + 2 * q;
+    int row_a, row_b;
+    if (PERM) {
+        if (ra + 1 < rows) {
+            const IV rr = *(const IV *)(row_order + ra);
+            row_a = rr[0];
+            row_b = rr[1];
+        } else {
+            row_a = row_b = row_order[min(ra, rows - 1)];
+        }
+    } else {
+        row_a = min(ra, rows - 1);
+        row_b = min(ra + 1, rows - 1);
+    }
+    const int r = ra + h;
+    const int out_row = h ? row_b : row_a;
+    const int64_t base = slice_ptr[s];
+    const int width = (int)((slice_ptr[s + 1] - base) >> 6);
+    const double *v = sval + base + q * 2;
+    const int *c = scol + base + q * 2;
+    const int *dg = sdiag + (base >> 6);
+    const int last = max(cols - 1, 0);
+    const double x0 = width > 0 ? x[0] : 0.0;
+    double acc = 0;
+    const int steps = (width + 1) / 2;
+    for (int jj = 0; jj < steps; jj += U) {
+        IV cc[U];
+        TV vv[U];
+        bool dia0[U], dia1[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const TV *p = (const TV *)(v + (int64_t)min(2 * (jj + u) + h, width - 1) * kWave);
+            vv[u] = NT ? __builtin_nontemporal_load(p) : *p;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int j0 = min(2 * (jj + u), width - 1), j1 = min(2 * (jj + u) + 1, width - 1);
+            const int d0 = __builtin_amdgcn_readfirstlane(dg[j0]), d1 = __builtin_amdgcn_readfirstlane(dg[j1]);
+            dia0[u] = d0 != INT_MIN;
+            dia1[u] = d1 != INT_MIN;
+            if (dia0[u] && dia1[u]) {
+                const int d = h ? d1 : d0;
+                cc[u][0] = min(max(row_a + d, 0), last);
+                cc[u][1] = min(max(row_b + d, 0), last);
+            } else {
+                const IV *p = (const IV *)(c + (int64_t)(h ? j1 : j0) * kWave);
+                const IV ld = NT ? __builtin_nontemporal_load(p) : *p;
+                const int d = h ? d1 : d0;
+                const bool mine = d != INT_MIN;
+                cc[u][0] = mine ? min(max(row_a + d, 0), last) : ld[0];
+                cc[u][1] = mine ? min(max(row_b + d, 0), last) : ld[1];
+            }
+        }
+        TV xx[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            xx[u][0] = x[cc[u][0]];
+            xx[u][1] = x[cc[u][1]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            double xa = xx[u][0], xb = xx[u][1], va = vv[u][0], vb = vv[u][1];
+            swap_half_waves(xa, xb);
+            swap_half_waves(va, vb);
+            // (xa, va): this lane's row at column 2 (jj + u); (xb, vb): at the column after it
+            const int col = 2 * (jj + u);
+            if (col < width) acc = fma_t(dia0[u] && va == 0.0 ? x0 : xa, va, acc);
+            if (col + 1 < width) acc = fma_t(dia1[u] && vb == 0.0 ? x0 : xb, vb, acc);
+        }
+    }
+    if (r < rows) y[out_row] = acc;
+}
+
 // sliced64_diag_kernel: the exact-order kernel for slices whose columns run along diagonals.  The
 // build pass left one number per slice column (sdiag): the distance col - row when all real entries
 // of the column share it, INT_MIN otherwise.  For a diagonal column the 64 column indices are not
@@ -1245,9 +1418,15 @@ int variant_candidates(const spmv_hip_matrix *m, int *out, int max_out)
     } else if (sliced64) {
         for (int v : kSlicedVariants)
             if (n < max_out) out[n++] = v;
+        if (m->dtype == SPMV_HIP_F64)                         // 16-byte loads in the exact summation order
+            for (int v : {24, 25, 26, 27})
+                if (n < max_out) out[n++] = v;
         // the kernels that skip the indices of diagonal columns, when at least half the columns are
         if (m->d_sdiag && m->diag_columns * 2 * kWave >= m->stored)
             for (int v : {16, 17, 18, 19, 20, 21, 22, 23})
+                if (n < max_out) out[n++] = v;
+        if (m->d_sdiag && m->diag_columns * 2 * kWave >= m->stored && m->dtype == SPMV_HIP_F64)
+            for (int v : {28, 29, 30, 31})                    // ... with 16-byte value loads
                 if (n < max_out) out[n++] = v;
     } else if (m->format == SPMV_HIP_CSR_VECTOR) {
         // vector CSR: candidates are (lanes per row) + 256 * (variant = rows side by side, see launch_csr_vector)
@@ -1287,7 +1466,7 @@ int variant_candidates(const spmv_hip_matrix *m, int *out, int max_out)
 
 // Whether `candidate` (as listed by variant_candidates) gives y the same bits as the handle's
 // current setting -- what spmv_hip_analyze may choose from under the option "exact_order".
-//   sliced formats of height 64: 0 and 16..23 keep the order of mult_csr_base; 1..12 reassociate.
+//   sliced formats of height 64: 0 and 16..31 keep the order of mult_csr_base; 1..12 reassociate.
 //   padding-free SELL, lane-per-row CSR: every variant sums alike.
 //   merge-path / balanced tiles: a tile that lies inside one row adds its entries per lane before the
 //     butterfly, and which lane holds which entry depends on where the loads start -- at the tile's
@@ -1331,6 +1510,39 @@ static int launch_sliced64(const spmv_hip_matrix *m, const T *x, T *y, hipStream
     case 10: SPMV_WIDE(4, true); break;
     case 11: SPMV_WIDE(7, true); break;
     case 12: SPMV_WIDE(14, true); break;
+#define SPMV_WIDE_EXACT(V, U, NT)                                                                          \
+    case V:                                                                                                \
+        if constexpr (std::is_same<T, double>::value) {                                                    \
+            hipLaunchKernelGGL((sliced64_wide_exact_kernel<PERM, U, NT>), grid, block, 0, st, m->rows, m->nslices, \
+                               m->d_slice_ptr, m->d_row_order, m->d_scol, sv, x, y, m->block_map);         \
+        } else {                                                                                           \
+            set_error("sliced format: variant %d is an fp64 kernel", V);                                   \
+            return 1;                                                                                      \
+        }                                                                                                  \
+        break;
+        // 24..27 (fp64): 16-byte loads with the exact summation order (7, 14 steps per batch; 26, 27 non-temporal)
+        SPMV_WIDE_EXACT(24, 7, false)
+        SPMV_WIDE_EXACT(25, 14, false)
+        SPMV_WIDE_EXACT(26, 7, true)
+        SPMV_WIDE_EXACT(27, 14, true)
+#undef SPMV_WIDE_EXACT
+#define SPMV_DIAG_WIDE(V, U, NT)                                                                           \
+    case V:                                                                                                \
+        if (!m->d_sdiag && m->stored > 0) { set_error("sliced format: variant %d needs the diagonal descriptors", V); return 1; } \
+        if constexpr (std::is_same<T, double>::value) {                                                    \
+            hipLaunchKernelGGL((sliced64_diag_wide_kernel<PERM, U, NT>), grid, block, 0, st, m->rows, m->columns, m->nslices, \
+                               m->d_slice_ptr, m->d_row_order, m->d_sdiag, m->d_scol, sv, x, y, m->block_map); \
+        } else {                                                                                           \
+            set_error("sliced format: variant %d is an fp64 kernel", V);                                   \
+            return 1;                                                                                      \
+        }                                                                                                  \
+        break;
+        // 28..31 (fp64): the same with the indices of diagonal slice columns not read (7, 4 steps; 30, 31 non-temporal)
+        SPMV_DIAG_WIDE(28, 7, false)
+        SPMV_DIAG_WIDE(29, 4, false)
+        SPMV_DIAG_WIDE(30, 7, true)
+        SPMV_DIAG_WIDE(31, 4, true)
+#undef SPMV_DIAG_WIDE
 #define SPMV_DIAG(V, U, NT)                                                                                \
     case V:                                                                                                \
         if (!m->d_sdiag && m->stored > 0) { set_error("sliced format: variant %d needs the diagonal descriptors", V); return 1; } \

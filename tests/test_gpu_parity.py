@@ -284,7 +284,7 @@ def test_sliced_wide_variants_and_analyze(orc, g, fmt):
             assert not np.isnan(y).any()
             assert rel(orc, y, ref) <= tol, (v, dtype)
         chosen = m.analyze(2)
-        assert chosen in [0] + SLICED_VARIANTS + DIAG_VARIANTS
+        assert chosen in [0] + SLICED_VARIANTS + DIAG_VARIANTS + [24, 25, 26, 27, 28, 29, 30, 31]
         assert rel(orc, m.mult(xin), ref) <= tol
         with pytest.raises(S.SpmvHipError, match="variant"):
             m.set_option("variant", 99)
@@ -721,3 +721,43 @@ def test_block_map_leaves_the_bits_alone(g):
             with pytest.raises(S.SpmvHipError, match="block_map"):
                 m.set_option("block_map", -1)
             m.free()
+
+
+WIDE_EXACT_VARIANTS = [24, 25, 26, 27, 28, 29, 30, 31]
+
+
+@pytest.mark.parametrize("fmt", ["sell", "sell64", "sellp", "ell"])
+def test_sliced_wide_exact_variants_bitwise(orc, g, fmt):
+    """16-byte loads with the rows handed back to single lanes by half-wave swaps (fp64 variants 24..27, and 28..31, which also leave the indices of diagonal slice columns unread): every row is
+    summed by one lane in ascending column order, so y is bit-identical to the reference's y_csr_base on every fixture
+    (odd and even slice widths, ragged last slices, empty rows); an fp32 handle refuses them."""
+    rows, cols = int(g["rows"]), int(g["cols"])
+    csr = (g["csr1_row_ptr"], g["csr1_col"], g["csr1_val"])
+
+    def make(dtype):
+        if fmt == "sell":
+            return Matrix.sell(rows, cols, *csr, dtype, 64, 1024)
+        if fmt == "sell64":
+            return Matrix.sell(rows, cols, *csr, dtype, 64, 64)
+        if fmt == "sellp":
+            return Matrix.sellp(rows, cols, *csr, dtype, 64)
+        return Matrix.ell(rows, cols, coo_of(g, "in"), dtype, 64)
+
+    m = make(S.F64)
+    for v in WIDE_EXACT_VARIANTS:
+        m.set_option("variant", v)
+        for bmap in (0, 2):
+            m.set_option("block_map", bmap)
+            assert bits_equal(m.mult(g["x"]), g["y_csr_base"]), (fmt, v, bmap)
+    m.set_option("block_map", 0)
+    m.set_option("exact_order", 1)
+    chosen = m.analyze(2)
+    assert chosen == 0 or chosen >= 16
+    assert bits_equal(m.mult(g["x"]), g["y_csr_base"]), chosen
+    m.free()
+    m = make(S.F32)
+    if m.info.stored > 0:
+        with pytest.raises(S.SpmvHipError, match="fp64"):
+            m.set_option("variant", 24)
+            m.mult(g["x"])
+    m.free()

@@ -18,7 +18,7 @@ from spmv_amd.matrix import Matrix, make_coo, coo_to_csr_host
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
 
-EXACT_SLICED = [0, 16, 17, 18, 19, 20, 21, 22, 23]
+EXACT_SLICED = [0, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31]
 REASSOC_SLICED = [1, 2, 3, 4, 9, 10, 11, 12]
 
 

@@ -84,7 +84,7 @@ def main():
             print(f"  ... {name} {dname}: timing", flush=True)
             try:
                 if args.variants == "general":
-                    trial = base + ["--variants", every_index[fmt]]
+                    trial = base + ["--variants", every_index[fmt] + (",24,25,26,27" if fmt in ("sell", "sellp", "ell") and dname == "f64" else "")]
                     if fmt == "csr_vector":                       # the LDS-staged kernel at 2, 4, 8 lanes per row
                         trial += ["--p0", "2,4,8"]
                     best = min(tune(trial, 8, every=True), key=lambda r: r["median_ms"])

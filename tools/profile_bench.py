@@ -30,9 +30,10 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 STEPS, WARMUP = 10, 3
-# what the kernel trial chooses from on the headline matrix: the 27-column batch of the index-skipping kernel with and
-# without non-temporal loads, the widest 16-byte-load kernels likewise; every block_map the trial compares
-SWEEP_SELL_VARIANTS = "18,22,21,4,12"
+# what the kernel trial chooses from on the headline matrix: the index-skipping kernels (27 columns per batch with 8-byte
+# loads, 14 with 16-byte loads) and the widest every-index kernels, each with and without non-temporal loads; every block_map
+# the trial compares
+SWEEP_SELL_VARIANTS = "18,22,28,30,4,12,24,26"
 SWEEP_MAPS = "0,1,2,3,4,5,8"
 SHORT = (("wave_tile", "tile"), ("tile_fixup", "fixup"), ("permute_x", "permute_x"), ("sum_partials", "sum_partials"))
 PRODUCT_KERNELS = re.compile(r"spmv::(sliced|csr_|wave_tile|tile_fixup|permute_x|sum_partials|sell_dfc)")
