@@ -607,7 +607,8 @@ __global__ __launch_bounds__(kBlock) void sliced64_wide_exact_kernel(int rows, i
 // takes its x operands from x[row + d] (its 64 indices stay unread), any other column reads its two indices; the
 // half-wave swap then hands each row's entries of columns 2jj, 2jj + 1 to one lane, which adds them in ascending
 // column order.  Same operands and order as sliced64_diag_kernel (padding lanes of described columns take x[0]),
-// so the same bits.
+// so the same bits.  Where a lane's two rows are neighbours their operands of a described column are neighbours
+// in x too and come with one 16-byte gather.
 template <bool PERM, int U, bool NT>
 __global__ __launch_bounds__(kBlock) void sliced64_diag_wide_kernel(int rows, int cols, int nslices,
                                                                     const int64_t *__restrict__ slice_ptr,
@@ -643,6 +644,10 @@ __global__ __launch_bounds__(kBlock) void sliced64_diag_wide_kernel(int rows, in
     }
     const int r = ra + h;
     const int out_row = h ? row_b : row_a;
+    // a slice whose row pairs are all neighbours (always without a row order; with one, wherever the window sort
+    // left no hole) takes the two x operands of a diagonal column, x[row + d] and x[row + 1 + d], with one 16-byte load
+    const bool all_adjacent = __ballot(row_b != row_a + 1) == 0;                    // wave-uniform
+    typedef double TVU __attribute__((ext_vector_type(2), aligned(8)));
     const int64_t base = slice_ptr[s];
     const int width = (int)((slice_ptr[s + 1] - base) >> 6);
     const double *v = sval + base + q * 2;
@@ -655,7 +660,7 @@ __global__ __launch_bounds__(kBlock) void sliced64_diag_wide_kernel(int rows, in
     for (int jj = 0; jj < steps; jj += U) {
         IV cc[U];
         TV vv[U];
-        bool dia0[U], dia1[U];
+        bool dia0[U], dia1[U], pair[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const TV *p = (const TV *)(v + (int64_t)min(2 * (jj + u) + h, width - 1) * kWave);
@@ -667,9 +672,12 @@ __global__ __launch_bounds__(kBlock) void sliced64_diag_wide_kernel(int rows, in
             const int d0 = __builtin_amdgcn_readfirstlane(dg[j0]), d1 = __builtin_amdgcn_readfirstlane(dg[j1]);
             dia0[u] = d0 != INT_MIN;
             dia1[u] = d1 != INT_MIN;
+            pair[u] = false;
             if (dia0[u] && dia1[u]) {
                 const int d = h ? d1 : d0;
-                cc[u][0] = min(max(row_a + d, 0), last);
+                const int ca = row_a + d;
+                pair[u] = all_adjacent && __ballot(!(ca >= 0 && ca < last)) == 0;   // wave-uniform
+                cc[u][0] = min(max(ca, 0), last);
                 cc[u][1] = min(max(row_b + d, 0), last);
             } else {
                 const IV *p = (const IV *)(c + (int64_t)(h ? j1 : j0) * kWave);
@@ -683,8 +691,14 @@ __global__ __launch_bounds__(kBlock) void sliced64_diag_wide_kernel(int rows, in
         TV xx[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            xx[u][0] = x[cc[u][0]];
-            xx[u][1] = x[cc[u][1]];
+            if (pair[u]) {
+                const TVU two = *(const TVU *)(x + cc[u][0]);
+                xx[u][0] = two[0];
+                xx[u][1] = two[1];
+            } else {
+                xx[u][0] = x[cc[u][0]];
+                xx[u][1] = x[cc[u][1]];
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
