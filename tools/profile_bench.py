@@ -33,7 +33,7 @@ STEPS, WARMUP = 10, 3
 # what the kernel trial chooses from on the headline matrix: the index-skipping kernels (27 columns per batch with 8-byte
 # loads, 14 with 16-byte loads) and the widest every-index kernels, each with and without non-temporal loads; every block_map
 # the trial compares
-SWEEP_SELL_VARIANTS = "18,22,28,30,4,12,24,26"
+SWEEP_SELL_VARIANTS = "18,22,28,29,30,31,4,12,24,26"
 SWEEP_MAPS = "0,1,2,3,4,5,8"
 SHORT = (("wave_tile", "tile"), ("tile_fixup", "fixup"), ("permute_x", "permute_x"), ("sum_partials", "sum_partials"))
 PRODUCT_KERNELS = re.compile(r"spmv::(sliced|csr_|wave_tile|tile_fixup|permute_x|sum_partials|sell_dfc)")
