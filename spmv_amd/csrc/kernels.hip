@@ -18,6 +18,9 @@
 //     index comes from, never the order or the operands.
 //   csr_vector: G interleaved partial sums per row + butterfly.
 //   sliced wide variants: 2 (fp64) / 4 (fp32) interleaved partial sums per row.
+//   sliced wide-exact variants (fp64): the wide variants' 16-byte loads, then a
+//     half-wave swap gives every lane one row's entries, added in ascending
+//     column order -- the order of mult_csr_base again.
 //   tile (merge-path / balanced): product rounded, then each row's products
 //     added in ascending order by one lane (rows longer than kLongRow: 64
 //     interleaved partial sums + butterfly); a row cut by tile boundaries gets
