@@ -140,7 +140,8 @@ def main():
     # 2. the counter passes
     table_path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     table = json.load(open(table_path)) if os.path.exists(table_path) else {}
-    table = {k: v for k, v in table.items() if isinstance(v, dict)}
+    # records taken on other kernel sources can no longer be reported: drop them
+    table = {k: v for k, v in table.items() if isinstance(v, dict) and v.get("kernel_sources_sha256") == bench.kernel_source_hash()}
     products = STEPS + WARMUP
     for n, (key, flags, split) in enumerate(configurations(line)):
         cmd = [py, script, "--steps", str(STEPS), "--warmup", str(WARMUP)] + flags
