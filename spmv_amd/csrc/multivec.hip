@@ -7,7 +7,8 @@
 // kernel here is lane-per-row with one fma per entry in ascending position, i.e. every column of
 // the result is bit-identical to mult_csr_base (reference csr.c:4-13) of that vector, whatever
 // the format of the handle:
-//   sliced formats of height 64 (SELL-C-sigma, SELLP, ELL)  -> sliced64_mv_kernel
+//   sliced formats of height 64 (SELL-C-sigma, SELLP, ELL)  -> sliced64_mv_kernel, and with described slice
+//                                                              columns and 2, 4, 8 vectors sliced64_mv_pair_kernel
 //   sliced formats of other heights                         -> sliced_any_mv_kernel
 //   SELL without padding                                    -> sell_dfc_mv_kernel
 //   CSR, merge-path CSR, balanced CSR (all hold plain CSR)  -> csr_rows_lds_mv_kernel
@@ -16,6 +17,7 @@
 #include "device_utils.h"
 
 #include <climits>
+#include <type_traits>
 
 namespace spmv {
 
@@ -92,6 +94,191 @@ __global__ __launch_bounds__(kBlock) void sliced64_mv_kernel(int rows, int cols,
     if (r < rows) {
 #pragma unroll
         for (int k = 0; k < NV; k++) y[k * ldy + row] = acc[k];
+    }
+}
+
+// Lane l takes `c` of lane l - 1 (UP) or of lane l + 1 (!UP) through a DPP wave shift; the lane that has no
+// such neighbour (0 / 63) keeps `edge`.  Every lane of the wave must be active.
+template <bool UP, typename T> __device__ __forceinline__ T neighbour_lane(T c, T edge)
+{
+    constexpr int ctrl = UP ? 0x138 : 0x130;                 // wave_shr:1 / wave_shl:1
+    if constexpr (sizeof(T) == 8) {
+        typedef int I2 __attribute__((ext_vector_type(2)));
+        const I2 cv = __builtin_bit_cast(I2, c), ev = __builtin_bit_cast(I2, edge);
+        I2 r;
+        r[0] = __builtin_amdgcn_update_dpp(ev[0], cv[0], ctrl, 0xf, 0xf, false);
+        r[1] = __builtin_amdgcn_update_dpp(ev[1], cv[1], ctrl, 0xf, 0xf, false);
+        return __builtin_bit_cast(T, r);
+    } else {
+        return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, c),
+                                                                 ctrl, 0xf, 0xf, false));
+    }
+}
+
+// The same product with two rows per lane, for matrices with described slice columns (sdiag not null) and an even
+// number of vectors.  With several vectors the lane-per-row kernels wait on many small gathers (8 bytes per lane,
+// three columns in flight).  Here lane (h, q) owns the rows at positions 2q, 2q + 1 of the slice for the vectors of
+// half h (NV / 2 of them), so that values, indices and results move as 16-byte pairs.  Where the slice's 64 rows are
+// neighbours in ascending order and three columns run along the distances d-1, d, d+1 (the x-neighbours of a grid
+// stencil), the 6 operands per lane and vector are 66 consecutive elements of x per wave: every lane loads its rows'
+// middle operands x[row + d] as one pair, the outer ones are the neighbour lanes' middle operands (DPP wave shifts),
+// and the two elements beside the window come for all vectors of the half in one load.  Two such runs are loaded
+// together before either is added.  Each row still adds its entries in ascending position with one fma each, on the
+// same operands: the bits are those of the lane-per-row kernel.
+template <typename T, bool PERM, int NV, bool NT>
+__global__ __launch_bounds__(kBlock) void sliced64_mv_pair_kernel(int rows, int cols, int nslices,
+                                                                  const int64_t *__restrict__ slice_ptr,
+                                                                  const int *__restrict__ row_order,
+                                                                  const int *__restrict__ sdiag,
+                                                                  const int *__restrict__ scol,
+                                                                  const T *__restrict__ sval,
+                                                                  const T *__restrict__ x, int64_t ldx,
+                                                                  T *__restrict__ y, int64_t ldy, int map)
+{
+    static_assert(NV % 2 == 0, "the two half-waves share the vectors");
+    constexpr int HV = NV / 2, kHalf = kWave / 2;
+    typedef T TV2 __attribute__((ext_vector_type(2)));
+    typedef T TVU __attribute__((ext_vector_type(2), aligned(sizeof(T))));
+    typedef int IV2 __attribute__((ext_vector_type(2)));
+    unsigned b = xcd_block(blockIdx.x, gridDim.x, map);
+    int s = __builtin_amdgcn_readfirstlane((int)(b * (kBlock / kWave) + threadIdx.x / kWave));
+    if (s >= nslices) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int h = lane >> 5, q = lane & (kHalf - 1);
+    const int64_t base = slice_ptr[s];
+    const int width = (int)((slice_ptr[s + 1] - base) >> 6);
+    const TV2 *v = (const TV2 *)(sval + base) + q;           // column jj of the slice: v[jj * 32]
+    const IV2 *c = (const IV2 *)(scol + base) + q;
+    const int r = s * kWave + 2 * q;
+    const int ra = PERM ? row_order[min(r, rows - 1)] : min(r, rows - 1);
+    const int rb = PERM ? row_order[min(r + 1, rows - 1)] : min(r + 1, rows - 1);
+    const bool pairs = __ballot(r + 1 >= rows || rb != ra + 1) == 0;      // every lane's rows are neighbours
+    // the slice's 64 rows in ascending order without a gap (wave-uniform)
+    const int row0 = __builtin_amdgcn_readfirstlane(ra);
+    const bool in_order = __ballot(r + 1 >= rows || ra != row0 + 2 * q || rb != ra + 1) == 0;
+    const int *dg = sdiag + (base >> 6);
+    const int last = max(cols - 1, 0);
+    const T *xh = x + (int64_t)h * HV * ldx;
+    T *yh = y + (int64_t)h * HV * ldy;
+    T acca[HV], accb[HV];
+#pragma unroll
+    for (int i = 0; i < HV; i++) acca[i] = accb[i] = 0;
+    // In a described column a zero value marks a padding lane (the build pass describes no column that holds a
+    // real zero); padding is stored as (column 0, value 0) (sellcs_format.c:167,171), so its operand is x_v[0] --
+    // what the reference multiplies by zero.
+    // one column for any two rows
+    auto one_column = [&](int jj, int d) {
+        const TV2 vv = stream_load<TV2, NT>(v + (int64_t)jj * kHalf);
+        const bool dia = d != INT_MIN;
+        int ca, cb;
+        if (dia) {
+            ca = vv[0] == (T)0 ? 0 : min(max(ra + d, 0), last);
+            cb = vv[1] == (T)0 ? 0 : min(max(rb + d, 0), last);
+        } else {
+            const IV2 cc = stream_load<IV2, NT>(c + (int64_t)jj * kHalf);
+            ca = cc[0];
+            cb = cc[1];
+        }
+        T xa[HV], xb[HV];
+#pragma unroll
+        for (int i = 0; i < HV; i++) xa[i] = xh[i * ldx + ca];
+#pragma unroll
+        for (int i = 0; i < HV; i++) xb[i] = xh[i * ldx + cb];
+#pragma unroll
+        for (int i = 0; i < HV; i++) {
+            acca[i] = fma_t(xa[i], vv[0], acca[i]);
+            accb[i] = fma_t(xb[i], vv[1], accb[i]);
+        }
+    };
+    // a run: three columns at the distances d - 1, d, d + 1 whose operands x[row0 + d - 1 .. row0 + 64 + d] exist
+    struct run_data {
+        TV2 vv[3];
+        TVU mid[HV];     // x[ra + d], x[rb + d]
+        T beside;        // lane 2i: x[row0 + d - 1], lane 2i + 1: x[row0 + 64 + d], of the half's vector i
+    };
+    auto is_run = [&](int d0, int d1, int d2) {
+        return in_order && d0 != INT_MIN && d1 == d0 + 1 && d2 == d0 + 2 && row0 + d0 >= 0 && row0 + kWave - 1 + d2 <= last;
+    };
+    auto load_run = [&](int jj, int d, run_data &R) {
+#pragma unroll
+        for (int u = 0; u < 3; u++) R.vv[u] = stream_load<TV2, NT>(v + (int64_t)(jj + u) * kHalf);
+#pragma unroll
+        for (int i = 0; i < HV; i++) R.mid[i] = *(const TVU *)(xh + i * ldx + ra + d);
+        R.beside = 0;
+        if (q < 2 * HV) R.beside = xh[(q >> 1) * ldx + row0 + ((q & 1) ? kWave + d : d - 1)];
+    };
+    auto add_run = [&](const run_data &R) {
+        const bool padded = __ballot(R.vv[0][0] == (T)0 || R.vv[0][1] == (T)0 || R.vv[1][0] == (T)0 ||
+                                     R.vv[1][1] == (T)0 || R.vv[2][0] == (T)0 || R.vv[2][1] == (T)0) != 0;
+        auto sums = [&](auto check) {
+            constexpr bool CHECK = decltype(check)::value;
+#pragma unroll
+            for (int i = 0; i < HV; i++) {
+                T before = neighbour_lane<true>(R.mid[i][1], R.mid[i][1]);      // x[ra + d - 1]
+                T after = neighbour_lane<false>(R.mid[i][0], R.mid[i][0]);      // x[rb + d + 1]
+                const T outer = __shfl(R.beside, (lane & kHalf) + 2 * i + (q == kHalf - 1 ? 1 : 0));
+                if (q == 0) before = outer;
+                if (q == kHalf - 1) after = outer;
+                const T x0 = CHECK ? xh[i * ldx] : (T)0;
+                acca[i] = fma_t(CHECK && R.vv[0][0] == (T)0 ? x0 : before, R.vv[0][0], acca[i]);
+                accb[i] = fma_t(CHECK && R.vv[0][1] == (T)0 ? x0 : R.mid[i][0], R.vv[0][1], accb[i]);
+                acca[i] = fma_t(CHECK && R.vv[1][0] == (T)0 ? x0 : R.mid[i][0], R.vv[1][0], acca[i]);
+                accb[i] = fma_t(CHECK && R.vv[1][1] == (T)0 ? x0 : R.mid[i][1], R.vv[1][1], accb[i]);
+                acca[i] = fma_t(CHECK && R.vv[2][0] == (T)0 ? x0 : R.mid[i][1], R.vv[2][0], acca[i]);
+                accb[i] = fma_t(CHECK && R.vv[2][1] == (T)0 ? x0 : after, R.vv[2][1], accb[i]);
+            }
+        };
+        if (padded) sums(std::true_type{});
+        else sums(std::false_type{});
+    };
+    auto three_columns = [&](int jj, int d0, int d1, int d2) {
+        if (is_run(d0, d1, d2)) {
+            run_data R;
+            load_run(jj, d1, R);
+            add_run(R);
+        } else {
+            one_column(jj, d0);
+            one_column(jj + 1, d1);
+            one_column(jj + 2, d2);
+        }
+    };
+    int j = 0;
+    for (; j + 6 <= width; j += 6) {
+        int d[6];
+#pragma unroll
+        for (int u = 0; u < 6; u++) d[u] = __builtin_amdgcn_readfirstlane(dg[j + u]);
+        if (is_run(d[0], d[1], d[2]) && is_run(d[3], d[4], d[5])) {       // both in flight before either is added
+            run_data R0, R1;
+            load_run(j, d[1], R0);
+            load_run(j + 3, d[4], R1);
+            add_run(R0);
+            add_run(R1);
+        } else {
+            three_columns(j, d[0], d[1], d[2]);
+            three_columns(j + 3, d[3], d[4], d[5]);
+        }
+    }
+    for (; j + 3 <= width; j += 3)
+        three_columns(j, __builtin_amdgcn_readfirstlane(dg[j]), __builtin_amdgcn_readfirstlane(dg[j + 1]),
+                      __builtin_amdgcn_readfirstlane(dg[j + 2]));
+    for (; j < width; j++) one_column(j, __builtin_amdgcn_readfirstlane(dg[j]));
+    if (pairs) {                                  // neighbours in y as well: one 16-byte store per vector
+#pragma unroll
+        for (int i = 0; i < HV; i++) {
+            TVU two;
+            two[0] = acca[i];
+            two[1] = accb[i];
+            *(TVU *)(yh + i * ldy + ra) = two;
+        }
+    } else {
+        if (r < rows) {
+#pragma unroll
+            for (int i = 0; i < HV; i++) yh[i * ldy + ra] = acca[i];
+        }
+        if (r + 1 < rows) {
+#pragma unroll
+            for (int i = 0; i < HV; i++) yh[i * ldy + rb] = accb[i];
+        }
     }
 }
 
@@ -284,6 +471,19 @@ static int launch_block(const spmv_hip_matrix *m, const T *x, int64_t ldx, T *y,
             const dim3 grid(blocks_for(m->nslices, kBlock / kWave)), block(kBlock);
             // the diagonal descriptors pay when at least half the slice columns have one
             const int *diag = m->d_sdiag && m->diag_columns * 2 * kWave >= m->stored ? m->d_sdiag : nullptr;
+            if constexpr (NV % 2 == 0) {
+                if (diag) {                       // two rows per lane, runs of neighbouring distances over the lanes
+                    if (perm)
+                        hipLaunchKernelGGL((sliced64_mv_pair_kernel<T, true, NV, NT>), grid, block, 0, st, m->rows,
+                                           m->columns, m->nslices, m->d_slice_ptr, m->d_row_order, diag, m->d_scol, sv, x,
+                                           ldx, y, ldy, m->block_map);
+                    else
+                        hipLaunchKernelGGL((sliced64_mv_pair_kernel<T, false, NV, NT>), grid, block, 0, st, m->rows,
+                                           m->columns, m->nslices, m->d_slice_ptr, m->d_row_order, diag, m->d_scol, sv, x,
+                                           ldx, y, ldy, m->block_map);
+                    break;
+                }
+            }
             if (perm)
                 hipLaunchKernelGGL((sliced64_mv_kernel<T, true, NV, U, NT>), grid, block, 0, st, m->rows, m->columns,
                                    m->nslices, m->d_slice_ptr, m->d_row_order, diag, m->d_scol, sv, x,

@@ -141,7 +141,30 @@ def test_c2_stencil_252_against_the_oracle(orc):
     for v in (0, 22):
         sellp.set_option("variant", v)
         assert _mult(sellp, x, rows).cpu().numpy().tobytes() == want.tobytes(), ("sellp", v)
+    # a block of vectors (two rows per lane, operands of neighbouring diagonals shifted over the lanes): every
+    # result column has the bits of its single product
+    st = torch.cuda.current_stream().cuda_stream
+    X = torch.stack([x, z, 2.0 * x - 3.0 * z, x * z, x, z, -x, 0.5 * z, z - x, x + 1.0])
+    Y = torch.empty(X.shape[0], rows, dtype=torch.float64, device=DEV)
+    sellp.set_option("variant", 0)
+    for nv in (8, 10, 2):
+        Y.fill_(-1.0)
+        sellp.mult_mv_dev(nv, X.data_ptr(), cols, Y.data_ptr(), rows, st)
+        torch.cuda.synchronize()
+        assert Y[0].cpu().numpy().tobytes() == want.tobytes(), ("sellp mult_mv", nv)
+        for k in range(1, nv):
+            assert torch.equal(Y[k], _mult(sellp, X[k], rows)), ("sellp mult_mv", nv, k)
     sellp.free()
+    sell = _dev_matrix(S.SELL, rows, cols, rp, cj, va, 64, 1024)
+    Y.fill_(-1.0)
+    sell.mult_mv_dev(4, X.data_ptr(), cols, Y.data_ptr(), rows, st)
+    torch.cuda.synchronize()
+    assert Y[0].cpu().numpy().tobytes() == want.tobytes(), "sell mult_mv"
+    for k in range(1, 4):
+        assert torch.equal(Y[k], _mult(sell, X[k], rows)), ("sell mult_mv", k)
+    sell.free()
+    del X, Y
+    torch.cuda.empty_cache()
 
     # ---- lane-per-row CSR, plain and with patterned row blocks
     scalar = _dev_matrix(S.CSR_SCALAR, rows, cols, rp, cj, va)

@@ -116,3 +116,81 @@ def test_mult_mv_empty_matrix(orc):
         Y = m.mult_mv(np.ones((3, 3)))
         assert Y.shape == (3, 5) and np.all(Y == 0.0), name
         m.free()
+
+
+def _band_csr(n, half, short_every=0, drop=0):
+    """Row i holds the columns i-half .. i+half that exist; every `short_every`-th row lacks its last `drop` entries
+    (in a sliced layout those positions are padding inside otherwise regular slice columns)."""
+    rp, cj = [0], []
+    for i in range(n):
+        cols_i = [c for c in range(i - half, i + half + 1) if 0 <= c < n]
+        if short_every and i % short_every == short_every - 1:
+            cols_i = cols_i[:max(len(cols_i) - drop, 1)]
+        cj += cols_i
+        rp.append(len(cj))
+    rng = np.random.default_rng(n + half)
+    return (n, n, np.asarray(rp, np.int32), np.asarray(cj, np.int32), rng.uniform(0.5, 1.5, len(cj)))
+
+
+RUN_CASES = {
+    "band_1": _band_csr(700, 1),                        # one run of three columns
+    "band_4": _band_csr(5000, 4),                       # three runs
+    "band_7": _band_csr(3000, 7),                       # five runs: two pairs and a single one
+    "band_13": _band_csr(2100, 13),                     # 27 columns like the 27-point stencil
+    "band_4_short_rows": _band_csr(4000, 4, 50, 3),     # padding inside runs
+    "band_5": _band_csr(1500, 5),                       # 11 columns: runs and two columns left over
+}
+
+
+def _same_bits_or_both_nan(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    nan = np.isnan(a)
+    return np.array_equal(nan, np.isnan(b)) and bits_equal(np.where(nan, 0.0, a), np.where(nan, 0.0, b))
+
+
+@pytest.mark.parametrize("case", sorted(RUN_CASES))
+def test_mult_mv_runs_of_neighbouring_diagonals_bitwise(orc, case):
+    """Slices of 64 neighbouring rows whose columns run along neighbouring diagonals take the two-rows-per-lane
+    kernel's shifted operands: same bits as n single products, for any stride, with padding and non-finite x."""
+    rows, cols, rp, cj, va = RUN_CASES[case]
+    rng = np.random.default_rng(11)
+    builders = _builders(rows, cols, rp, cj, va)
+    for name in ("sellp", "sell_1024", "ell"):
+        m = builders[name](S.F64)
+        assert m.info.diag_columns * 2 * 64 >= m.info.stored, (case, name)      # the kernel with the runs is the one launched
+        for n in (2, 4, 6, 8, 13):
+            X = rng.standard_normal((n, cols))
+            assert bits_equal(m.mult_mv(X), orc.mult_mv_csr(rp, cj, va, X)), (case, name, n)
+        # vectors an odd number of elements apart (pairs of operands and results off their 16-byte alignment)
+        n, ldx, ldy = 8, cols + 37, rows + 11
+        xb = torch.from_numpy(rng.standard_normal((n, ldx))).cuda()
+        yb = torch.full((n, ldy), -7.0, dtype=torch.float64, device="cuda")
+        m.mult_mv_dev(n, xb.data_ptr(), ldx, yb.data_ptr(), ldy, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = yb.cpu().numpy()
+        assert bits_equal(np.ascontiguousarray(got[:, :rows]),
+                          orc.mult_mv_csr(rp, cj, va, np.ascontiguousarray(xb.cpu().numpy()[:, :cols]))), (case, name)
+        assert np.all(got[:, rows:] == -7.0)
+        # x[0] is what the padding of a sliced layout multiplies (sellcs_format.c:167,171; sellp.c:440-452): NaN / inf
+        # there, and inside the band -- against the oracle's restatement of the reference's sliced kernels
+        if name != "ell":
+            X = rng.standard_normal((4, cols))
+            X[0, 0] = np.nan
+            X[1, 0] = np.inf
+            X[2, cols // 2] = np.inf
+            X[3, cols - 1] = np.nan
+            with np.errstate(invalid="ignore"):
+                if name == "sellp":
+                    layout = orc.sliced_ell_from_csr(rp, cj, va, 64)
+                    want = np.stack([orc.mult_sliced_ell(layout, X[k])[:rows] for k in range(4)])
+                else:
+                    layout = orc.sell_from_csr(rp, cj, va, 64, 1024)
+                    want = np.stack([orc.mult_sell(layout, X[k])[:rows] for k in range(4)])
+            assert _same_bits_or_both_nan(m.mult_mv(X), want), (case, name)
+        m.free()
+        m = builders[name](S.F32)
+        X32 = rng.standard_normal((6, cols)).astype(np.float32)
+        Y = m.mult_mv(X32.astype(np.float64)).astype(np.float32)
+        for v in range(6):
+            assert bits_equal(Y[v], orc.mult_csr_base_f32(rp, cj, va.astype(np.float32), X32[v])), (case, name, v)
+        m.free()
