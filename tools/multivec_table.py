@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--vectors", default="1,2,4,8,16")
     ap.add_argument("--dtypes", default="f64")
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--block-maps", default="", help="comma list: time the block products under these block_map values "
+                    "instead of the one analyze picked for single products")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     if args.matrix == "stencil27":
@@ -64,11 +66,16 @@ def main():
             m = Matrix.from_device_csr(fmt, rows, cols, nnz, rp.data_ptr(), cj.data_ptr(), vals.data_ptr(), dtype, p0, p1, st)
             m.analyze(3)
             single = median_ms(lambda: m.mult_dev(x.data_ptr(), y.data_ptr(), st), args.steps)
+            maps = [int(v) for v in args.block_maps.split(",")] if args.block_maps else [None]
             for n in (int(v) for v in args.vectors.split(",")):
-                ms = median_ms(lambda: m.mult_mv_dev(n, x.data_ptr(), cols, y.data_ptr(), rows, st), args.steps)
-                b_alg = nnz * (vb + 4) + rows * (4 + n * vb) + cols * n * vb
-                print(f"| {name} | {dname} | {n} | {ms:.3f} | {single * n:.3f} | {2 * nnz * n / ms / 1e6:.0f} | "
-                      f"{b_alg / ms / 1e6:.0f} | {b_alg / ms / 1e6 / 80:.1f} |", flush=True)
+                for bm in maps:
+                    if bm is not None:
+                        m.set_option("block_map", bm)
+                    ms = median_ms(lambda: m.mult_mv_dev(n, x.data_ptr(), cols, y.data_ptr(), rows, st), args.steps)
+                    b_alg = nnz * (vb + 4) + rows * (4 + n * vb) + cols * n * vb
+                    label = name if bm is None else f"{name} block_map {bm}"
+                    print(f"| {label} | {dname} | {n} | {ms:.3f} | {single * n:.3f} | {2 * nnz * n / ms / 1e6:.0f} | "
+                          f"{b_alg / ms / 1e6:.0f} | {b_alg / ms / 1e6 / 80:.1f} |", flush=True)
             m.free()
             torch.cuda.empty_cache()
 
