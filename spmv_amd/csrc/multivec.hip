@@ -2,16 +2,17 @@
 // declares as mult_mv_csr(struct csr *, int n, double *x, double *y) (src/spmv.h:54) and never
 // defines.  Vector v is the contiguous array x + v*ldx, its result y + v*ldy.
 //
-// The matrix is streamed once for NV vectors at a time (NV = 8, 4, 2, then 1 for an odd last
-// vector), so its 12 bytes per entry are shared by NV products.  Every
+// The matrix is streamed once for NV vectors at a time (blocks of 8, then the 1..7 that are left),
+// so its 12 bytes per entry are shared by NV products.  Every
 // kernel here is lane-per-row with one fma per entry in ascending position, i.e. every column of
 // the result is bit-identical to mult_csr_base (reference csr.c:4-13) of that vector, whatever
 // the format of the handle:
-//   sliced formats of height 64 (SELL-C-sigma, SELLP, ELL)  -> sliced64_mv_kernel, and with described slice
-//                                                              columns and 2, 4, 8 vectors sliced64_mv_pair_kernel
+//   sliced formats of height 64 (SELL-C-sigma, SELLP, ELL)  -> sliced64_mv_kernel; with described slice columns
+//                                                              and two or more vectors sliced64_mv_rows_kernel
 //   sliced formats of other heights                         -> sliced_any_mv_kernel
 //   SELL without padding                                    -> sell_dfc_mv_kernel
-//   CSR, merge-path CSR, balanced CSR (all hold plain CSR)  -> csr_rows_lds_mv_kernel
+//   CSR, merge-path CSR, balanced CSR (all hold plain CSR)  -> csr_rows_gather_mv_kernel (one vector:
+//                                                              csr_rows_lds_mv_kernel)
 
 #include "internal.h"
 #include "device_utils.h"
@@ -115,18 +116,18 @@ template <bool UP, typename T> __device__ __forceinline__ T neighbour_lane(T c, 
     }
 }
 
-// The same product with two rows per lane, for matrices with described slice columns (sdiag not null) and an even
-// number of vectors.  With several vectors the lane-per-row kernels wait on many small gathers (8 bytes per lane,
-// three columns in flight).  Here lane (h, q) owns the rows at positions 2q, 2q + 1 of the slice for the vectors of
-// half h (NV / 2 of them), so that values, indices and results move as 16-byte pairs.  Where the slice's 64 rows are
-// neighbours in ascending order and three columns run along the distances d-1, d, d+1 (the x-neighbours of a grid
-// stencil), the 6 operands per lane and vector are 66 consecutive elements of x per wave: every lane loads its rows'
-// middle operands x[row + d] as one pair, the outer ones are the neighbour lanes' middle operands (DPP wave shifts),
-// and the two elements beside the window come for all vectors of the half in one load.  Two such runs are loaded
-// together before either is added.  Each row still adds its entries in ascending position with one fma each, on the
-// same operands: the bits are those of the lane-per-row kernel.
+// The same product for matrices with described slice columns (sdiag not null) and two or more vectors.  With several
+// vectors the product waits on its many small gathers; what a gather costs the CU's texture addresser hardly depends
+// on its active lanes or bytes, so the count of vector memory instructions is what to cut.  Where a slice's 64 rows
+// are neighbours in ascending order and three columns run along the distances d-1, d, d+1 (the x-neighbours of a
+// grid stencil), lane l's operands are x[row + d - 1 .. row + d + 1] = the middle operands of lanes l-1, l, l+1:
+// every vector gathers the middle column once with all lanes, the outer two come over the lanes (DPP wave shifts),
+// and the element before lane 0's and after lane 63's window come for ALL vectors in one load (lane 2v: before,
+// lane 2v + 1: after, of vector v).  Two or three such runs are in flight together.  Same operands, same order of
+// the sums: the bits of sliced64_mv_kernel.  A zero value in a described column is padding and multiplies x_v[0]
+// (sellcs_format.c:167,171), as there.
 template <typename T, bool PERM, int NV, bool NT>
-__global__ __launch_bounds__(kBlock) void sliced64_mv_pair_kernel(int rows, int cols, int nslices,
+__global__ __launch_bounds__(kBlock) void sliced64_mv_rows_kernel(int rows, int cols, int nslices,
                                                                   const int64_t *__restrict__ slice_ptr,
                                                                   const int *__restrict__ row_order,
                                                                   const int *__restrict__ sdiag,
@@ -135,150 +136,101 @@ __global__ __launch_bounds__(kBlock) void sliced64_mv_pair_kernel(int rows, int 
                                                                   const T *__restrict__ x, int64_t ldx,
                                                                   T *__restrict__ y, int64_t ldy, int map)
 {
-    static_assert(NV % 2 == 0, "the two half-waves share the vectors");
-    constexpr int HV = NV / 2, kHalf = kWave / 2;
-    typedef T TV2 __attribute__((ext_vector_type(2)));
-    typedef T TVU __attribute__((ext_vector_type(2), aligned(sizeof(T))));
-    typedef int IV2 __attribute__((ext_vector_type(2)));
     unsigned b = xcd_block(blockIdx.x, gridDim.x, map);
     int s = __builtin_amdgcn_readfirstlane((int)(b * (kBlock / kWave) + threadIdx.x / kWave));
     if (s >= nslices) return;
     const int lane = threadIdx.x & (kWave - 1);
-    const int h = lane >> 5, q = lane & (kHalf - 1);
     const int64_t base = slice_ptr[s];
     const int width = (int)((slice_ptr[s + 1] - base) >> 6);
-    const TV2 *v = (const TV2 *)(sval + base) + q;           // column jj of the slice: v[jj * 32]
-    const IV2 *c = (const IV2 *)(scol + base) + q;
-    const int r = s * kWave + 2 * q;
-    const int ra = PERM ? row_order[min(r, rows - 1)] : min(r, rows - 1);
-    const int rb = PERM ? row_order[min(r + 1, rows - 1)] : min(r + 1, rows - 1);
-    const bool pairs = __ballot(r + 1 >= rows || rb != ra + 1) == 0;      // every lane's rows are neighbours
-    // the slice's 64 rows in ascending order without a gap (wave-uniform)
-    const int row0 = __builtin_amdgcn_readfirstlane(ra);
-    const bool in_order = __ballot(r + 1 >= rows || ra != row0 + 2 * q || rb != ra + 1) == 0;
+    const T *v = sval + base + lane;
+    const int *c = scol + base + lane;
+    const int r = s * kWave + lane;
+    const int row = PERM ? row_order[min(r, rows - 1)] : min(r, rows - 1);
+    const int row0 = __builtin_amdgcn_readfirstlane(row);
+    const bool in_order = __ballot(r >= rows || row != row0 + lane) == 0;
     const int *dg = sdiag + (base >> 6);
     const int last = max(cols - 1, 0);
-    const T *xh = x + (int64_t)h * HV * ldx;
-    T *yh = y + (int64_t)h * HV * ldy;
-    T acca[HV], accb[HV];
+    T acc[NV];
 #pragma unroll
-    for (int i = 0; i < HV; i++) acca[i] = accb[i] = 0;
-    // In a described column a zero value marks a padding lane (the build pass describes no column that holds a
-    // real zero); padding is stored as (column 0, value 0) (sellcs_format.c:167,171), so its operand is x_v[0] --
-    // what the reference multiplies by zero.
-    // one column for any two rows
+    for (int k = 0; k < NV; k++) acc[k] = 0;
     auto one_column = [&](int jj, int d) {
-        const TV2 vv = stream_load<TV2, NT>(v + (int64_t)jj * kHalf);
-        const bool dia = d != INT_MIN;
-        int ca, cb;
-        if (dia) {
-            ca = vv[0] == (T)0 ? 0 : min(max(ra + d, 0), last);
-            cb = vv[1] == (T)0 ? 0 : min(max(rb + d, 0), last);
-        } else {
-            const IV2 cc = stream_load<IV2, NT>(c + (int64_t)jj * kHalf);
-            ca = cc[0];
-            cb = cc[1];
-        }
-        T xa[HV], xb[HV];
+        const T vv = stream_load<T, NT>(v + (int64_t)jj * kWave);
+        int cc;
+        if (d != INT_MIN) cc = vv == (T)0 ? 0 : min(max(row + d, 0), last);
+        else cc = stream_load<int, NT>(c + (int64_t)jj * kWave);
+        T xx[NV];
 #pragma unroll
-        for (int i = 0; i < HV; i++) xa[i] = xh[i * ldx + ca];
+        for (int k = 0; k < NV; k++) xx[k] = x[k * ldx + cc];
 #pragma unroll
-        for (int i = 0; i < HV; i++) xb[i] = xh[i * ldx + cb];
-#pragma unroll
-        for (int i = 0; i < HV; i++) {
-            acca[i] = fma_t(xa[i], vv[0], acca[i]);
-            accb[i] = fma_t(xb[i], vv[1], accb[i]);
-        }
-    };
-    // a run: three columns at the distances d - 1, d, d + 1 whose operands x[row0 + d - 1 .. row0 + 64 + d] exist
-    struct run_data {
-        TV2 vv[3];
-        TVU mid[HV];     // x[ra + d], x[rb + d]
-        T beside;        // lane 2i: x[row0 + d - 1], lane 2i + 1: x[row0 + 64 + d], of the half's vector i
+        for (int k = 0; k < NV; k++) acc[k] = fma_t(xx[k], vv, acc[k]);
     };
     auto is_run = [&](int d0, int d1, int d2) {
         return in_order && d0 != INT_MIN && d1 == d0 + 1 && d2 == d0 + 2 && row0 + d0 >= 0 && row0 + kWave - 1 + d2 <= last;
     };
-    auto load_run = [&](int jj, int d, run_data &R) {
+    auto runs = [&](int jj, const int *dmid, auto count) {
+        constexpr int R = decltype(count)::value;
+        T vv[R][3], mid[R][NV], beside[R];
 #pragma unroll
-        for (int u = 0; u < 3; u++) R.vv[u] = stream_load<TV2, NT>(v + (int64_t)(jj + u) * kHalf);
+        for (int t = 0; t < R; t++) {
 #pragma unroll
-        for (int i = 0; i < HV; i++) R.mid[i] = *(const TVU *)(xh + i * ldx + ra + d);
-        R.beside = 0;
-        if (q < 2 * HV) R.beside = xh[(q >> 1) * ldx + row0 + ((q & 1) ? kWave + d : d - 1)];
-    };
-    auto add_run = [&](const run_data &R) {
-        const bool padded = __ballot(R.vv[0][0] == (T)0 || R.vv[0][1] == (T)0 || R.vv[1][0] == (T)0 ||
-                                     R.vv[1][1] == (T)0 || R.vv[2][0] == (T)0 || R.vv[2][1] == (T)0) != 0;
+            for (int u = 0; u < 3; u++) vv[t][u] = stream_load<T, NT>(v + (int64_t)(jj + 3 * t + u) * kWave);
+#pragma unroll
+            for (int k = 0; k < NV; k++) mid[t][k] = x[k * ldx + row + dmid[t]];
+            beside[t] = 0;
+            if (lane < 2 * NV) beside[t] = x[(lane >> 1) * ldx + row0 + ((lane & 1) ? kWave + dmid[t] : dmid[t] - 1)];
+        }
+        bool zero = false;
+#pragma unroll
+        for (int t = 0; t < R; t++) zero |= vv[t][0] == (T)0 || vv[t][1] == (T)0 || vv[t][2] == (T)0;
+        const bool padded = __ballot(zero) != 0;
         auto sums = [&](auto check) {
             constexpr bool CHECK = decltype(check)::value;
 #pragma unroll
-            for (int i = 0; i < HV; i++) {
-                T before = neighbour_lane<true>(R.mid[i][1], R.mid[i][1]);      // x[ra + d - 1]
-                T after = neighbour_lane<false>(R.mid[i][0], R.mid[i][0]);      // x[rb + d + 1]
-                const T outer = __shfl(R.beside, (lane & kHalf) + 2 * i + (q == kHalf - 1 ? 1 : 0));
-                if (q == 0) before = outer;
-                if (q == kHalf - 1) after = outer;
-                const T x0 = CHECK ? xh[i * ldx] : (T)0;
-                acca[i] = fma_t(CHECK && R.vv[0][0] == (T)0 ? x0 : before, R.vv[0][0], acca[i]);
-                accb[i] = fma_t(CHECK && R.vv[0][1] == (T)0 ? x0 : R.mid[i][0], R.vv[0][1], accb[i]);
-                acca[i] = fma_t(CHECK && R.vv[1][0] == (T)0 ? x0 : R.mid[i][0], R.vv[1][0], acca[i]);
-                accb[i] = fma_t(CHECK && R.vv[1][1] == (T)0 ? x0 : R.mid[i][1], R.vv[1][1], accb[i]);
-                acca[i] = fma_t(CHECK && R.vv[2][0] == (T)0 ? x0 : R.mid[i][1], R.vv[2][0], acca[i]);
-                accb[i] = fma_t(CHECK && R.vv[2][1] == (T)0 ? x0 : after, R.vv[2][1], accb[i]);
-            }
+            for (int t = 0; t < R; t++)
+#pragma unroll
+                for (int k = 0; k < NV; k++) {
+                    const T outer = __shfl(beside[t], 2 * k + (lane == kWave - 1 ? 1 : 0));
+                    const T lo = neighbour_lane<true>(mid[t][k], outer), hi = neighbour_lane<false>(mid[t][k], outer);
+                    const T x0 = CHECK ? x[k * ldx] : (T)0;
+                    acc[k] = fma_t(CHECK && vv[t][0] == (T)0 ? x0 : lo, vv[t][0], acc[k]);
+                    acc[k] = fma_t(CHECK && vv[t][1] == (T)0 ? x0 : mid[t][k], vv[t][1], acc[k]);
+                    acc[k] = fma_t(CHECK && vv[t][2] == (T)0 ? x0 : hi, vv[t][2], acc[k]);
+                }
         };
         if (padded) sums(std::true_type{});
         else sums(std::false_type{});
     };
-    auto three_columns = [&](int jj, int d0, int d1, int d2) {
-        if (is_run(d0, d1, d2)) {
-            run_data R;
-            load_run(jj, d1, R);
-            add_run(R);
-        } else {
-            one_column(jj, d0);
-            one_column(jj + 1, d1);
-            one_column(jj + 2, d2);
-        }
-    };
+    constexpr int RB = NV >= 5 ? 2 : 3;
     int j = 0;
-    for (; j + 6 <= width; j += 6) {
-        int d[6];
+    while (j < width) {
+        int d[3 * RB];
+        int nr = 0;
 #pragma unroll
-        for (int u = 0; u < 6; u++) d[u] = __builtin_amdgcn_readfirstlane(dg[j + u]);
-        if (is_run(d[0], d[1], d[2]) && is_run(d[3], d[4], d[5])) {       // both in flight before either is added
-            run_data R0, R1;
-            load_run(j, d[1], R0);
-            load_run(j + 3, d[4], R1);
-            add_run(R0);
-            add_run(R1);
+        for (int t = 0; t < RB; t++) {
+            if (nr == t && j + 3 * (t + 1) <= width) {
+                d[3 * t] = __builtin_amdgcn_readfirstlane(dg[j + 3 * t]);
+                d[3 * t + 1] = __builtin_amdgcn_readfirstlane(dg[j + 3 * t + 1]);
+                d[3 * t + 2] = __builtin_amdgcn_readfirstlane(dg[j + 3 * t + 2]);
+                if (is_run(d[3 * t], d[3 * t + 1], d[3 * t + 2])) nr = t + 1;
+            }
+        }
+        if (nr == RB) {
+            int dmid[RB];
+#pragma unroll
+            for (int t = 0; t < RB; t++) dmid[t] = d[3 * t + 1];
+            runs(j, dmid, std::integral_constant<int, RB>{});
+            j += 3 * RB;
+        } else if (nr >= 1) {
+            runs(j, &d[1], std::integral_constant<int, 1>{});
+            j += 3;
         } else {
-            three_columns(j, d[0], d[1], d[2]);
-            three_columns(j + 3, d[3], d[4], d[5]);
+            one_column(j, __builtin_amdgcn_readfirstlane(dg[j]));
+            j += 1;
         }
     }
-    for (; j + 3 <= width; j += 3)
-        three_columns(j, __builtin_amdgcn_readfirstlane(dg[j]), __builtin_amdgcn_readfirstlane(dg[j + 1]),
-                      __builtin_amdgcn_readfirstlane(dg[j + 2]));
-    for (; j < width; j++) one_column(j, __builtin_amdgcn_readfirstlane(dg[j]));
-    if (pairs) {                                  // neighbours in y as well: one 16-byte store per vector
+    if (r < rows) {
 #pragma unroll
-        for (int i = 0; i < HV; i++) {
-            TVU two;
-            two[0] = acca[i];
-            two[1] = accb[i];
-            *(TVU *)(yh + i * ldy + ra) = two;
-        }
-    } else {
-        if (r < rows) {
-#pragma unroll
-            for (int i = 0; i < HV; i++) yh[i * ldy + ra] = acca[i];
-        }
-        if (r + 1 < rows) {
-#pragma unroll
-            for (int i = 0; i < HV; i++) yh[i * ldy + rb] = accb[i];
-        }
+        for (int k = 0; k < NV; k++) y[k * ldy + row] = acc[k];
     }
 }
 
@@ -445,6 +397,151 @@ __global__ __launch_bounds__(kWave) void csr_rows_lds_mv_kernel(int rows, const 
     }
 }
 
+// The same product with the gathers made by rows.  The chunk parks only (column, value) -- for a patterned block the
+// value alone -- and every lane gathers the NV operands of its own row's entries, U entries at a time: one gather
+// instruction then touches the few lines of 64 neighbouring rows at one position of their rows (as in the sliced
+// kernels) instead of the lines of 64 consecutive entries of two or three rows.  A chunk of 64*IPL entries normally
+// holds the whole block, so that all 64 rows are busy.  Entry k sits at k + k/64 in LDS: rows of an even length
+// would otherwise meet on a few banks.
+template <typename T, int IPL, int NV, int U, bool NT>
+__global__ __launch_bounds__(kWave) void csr_rows_gather_mv_kernel(int rows, const int *__restrict__ row_ptr,
+                                                                   const int *__restrict__ col,
+                                                                   const T *__restrict__ val,
+                                                                   const unsigned char *__restrict__ pattern_len,
+                                                                   const int *__restrict__ row_map,
+                                                                   const T *__restrict__ x, int64_t ldx,
+                                                                   T *__restrict__ y, int64_t ldy, int map)
+{
+    constexpr int kCap = kWave * IPL;
+    __shared__ int scol[kCap + kCap / kWave];
+    __shared__ T sval[kCap + kCap / kWave];
+    __shared__ int dist[32];
+    auto skew = [](int k) { return k + (k >> 6); };
+    const int blk = (int)xcd_block(blockIdx.x, gridDim.x, map);
+    const int lane = threadIdx.x;
+    const int row = blk * kWave + lane;
+    const int last = min(blk * kWave + kWave, rows);
+    const int rs = row_ptr[min(row, rows)];
+    const int re = row < rows ? row_ptr[row + 1] : rs;
+    const int run_begin = __builtin_amdgcn_readfirstlane(rs);
+    const int run_end = row_ptr[last];
+    // wave-uniform: every row of a patterned block (all 64 rows inside the matrix) has the columns row + dist[0..L)
+    const int L = pattern_len && last == blk * kWave + kWave ? pattern_len[blk] : 0;
+    unsigned run_at = 0;                 // bit p: dist[p], dist[p + 1], dist[p + 2] are consecutive numbers
+    if (L) {
+        if (lane < L) dist[lane] = col[run_begin + lane] - blk * kWave;
+        __syncthreads();
+        run_at = (unsigned)__ballot(lane + 2 < L && dist[min(lane + 1, 31)] == dist[min(lane, 31)] + 1 &&
+                                    dist[min(lane + 2, 31)] == dist[min(lane, 31)] + 2);
+    }
+    // a patterned block that fits one chunk is walked by positions, all rows side by side
+    const bool by_position = L && run_end - (run_begin & ~31) <= kCap;
+    T acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) acc[k] = 0;
+    for (int e0 = run_begin & ~31; e0 < run_end; e0 += kCap) {
+        const int n = min(kCap, run_end - e0);
+        T vv[IPL];
+#pragma unroll
+        for (int i = 0; i < IPL; i++)
+            vv[i] = stream_load<T, NT>(val + min(max(e0 + lane + i * kWave, run_begin), run_end - 1));
+        if (!L) {
+            int cc[IPL];
+#pragma unroll
+            for (int i = 0; i < IPL; i++)
+                cc[i] = stream_load<int, NT>(col + min(max(e0 + lane + i * kWave, run_begin), run_end - 1));
+#pragma unroll
+            for (int i = 0; i < IPL; i++) scol[skew(lane + i * kWave)] = cc[i];
+        }
+#pragma unroll
+        for (int i = 0; i < IPL; i++) sval[skew(lane + i * kWave)] = vv[i];
+        __syncthreads();
+        if (by_position) {
+            // Three positions at consecutive distances d-1, d, d+1: the operands of lane l are x[row + d - 1 .. + 1] =
+            // the middle operands of lanes l-1, l, l+1.  All lanes gather the middle one; the outer two come over the
+            // lanes (DPP wave shifts); the element before row 0's and after row 63's window come for all vectors in
+            // one load (lane 2v: before, lane 2v + 1: after, of vector v).  R runs are in flight together.
+            const int mine = rs - e0;                            // this row's first entry in the chunk
+            const int row0 = blk * kWave;
+            auto runs = [&](int p, auto count) {
+                constexpr int R = decltype(count)::value;
+                T v[R][3], mid[R][NV], beside[R];
+#pragma unroll
+                for (int t = 0; t < R; t++) {
+#pragma unroll
+                    for (int u = 0; u < 3; u++) v[t][u] = sval[skew(mine + p + 3 * t + u)];
+                    const int d = dist[p + 3 * t + 1];
+#pragma unroll
+                    for (int kk = 0; kk < NV; kk++) mid[t][kk] = x[kk * ldx + row + d];
+                    beside[t] = 0;
+                    if (lane < 2 * NV) beside[t] = x[(lane >> 1) * ldx + row0 + ((lane & 1) ? kWave + d : d - 1)];
+                }
+#pragma unroll
+                for (int t = 0; t < R; t++)
+#pragma unroll
+                    for (int kk = 0; kk < NV; kk++) {
+                        const T outer = __shfl(beside[t], 2 * kk + (lane == kWave - 1 ? 1 : 0));
+                        const T lo = neighbour_lane<true>(mid[t][kk], outer), hi = neighbour_lane<false>(mid[t][kk], outer);
+                        acc[kk] = fma_t(lo, v[t][0], acc[kk]);
+                        acc[kk] = fma_t(mid[t][kk], v[t][1], acc[kk]);
+                        acc[kk] = fma_t(hi, v[t][2], acc[kk]);
+                    }
+            };
+            constexpr int RB = NV >= 5 ? 2 : 3;
+            int p = 0;
+            while (p < L) {
+                int nr = 0;
+                while (nr < RB && p + 3 * (nr + 1) <= L && ((run_at >> (p + 3 * nr)) & 1u)) nr++;
+                if (nr == RB) {
+                    runs(p, std::integral_constant<int, RB>{});
+                    p += 3 * RB;
+                } else if (nr >= 1) {
+                    runs(p, std::integral_constant<int, 1>{});
+                    p += 3;
+                } else {
+                    const T v = sval[skew(mine + p)];
+                    const int c = row + dist[p];
+                    T xv[NV];
+#pragma unroll
+                    for (int kk = 0; kk < NV; kk++) xv[kk] = x[kk * ldx + c];
+#pragma unroll
+                    for (int kk = 0; kk < NV; kk++) acc[kk] = fma_t(xv[kk], v, acc[kk]);
+                    p += 1;
+                }
+            }
+            break;                                               // the block was one chunk
+        }
+        int k = max(rs, e0) - e0;
+        const int kend = min(re, e0 + n) - e0;
+        for (; k < kend; k += U) {
+            int c[U];
+            T v[U], xv[U][NV];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int at = min(k + u, kend - 1);
+                v[u] = sval[skew(at)];
+                c[u] = L ? row + dist[e0 + at - rs] : scol[skew(at)];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int kk = 0; kk < NV; kk++) xv[u][kk] = x[kk * ldx + c[u]];
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (k + u < kend) {
+#pragma unroll
+                    for (int kk = 0; kk < NV; kk++) acc[kk] = fma_t(xv[u][kk], v[u], acc[kk]);
+                }
+        }
+        __syncthreads();
+    }
+    if (row < rows) {
+        const int dst = row_map ? row_map[row] : row;
+#pragma unroll
+        for (int k = 0; k < NV; k++) y[k * ldy + dst] = acc[k];
+    }
+}
+
 // ------------------------------------------------------------------ launchers --
 
 static inline unsigned blocks_for(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
@@ -452,15 +549,21 @@ static inline unsigned blocks_for(int64_t a, int64_t b) { return (unsigned)((a +
 template <typename T, int NV, bool NT>
 static int launch_block(const spmv_hip_matrix *m, const T *x, int64_t ldx, T *y, int64_t ldy, hipStream_t st)
 {
-    constexpr int U = NV >= 8 ? 2 : (NV == 4 ? 4 : 8);
+    constexpr int U = NV >= 7 ? 2 : NV >= 5 ? 3 : NV >= 3 ? 4 : 8;
     switch (m->format) {
     case SPMV_HIP_CSR_SCALAR:
     case SPMV_HIP_CSR_VECTOR:
     case SPMV_HIP_CSR_MERGE:
     case SPMV_HIP_CSR_BAL:
-        hipLaunchKernelGGL((csr_rows_lds_mv_kernel<T, 4, NV, NT>), dim3(blocks_for(m->rows, kWave)), dim3(kWave), 0, st,
-                           m->rows, m->d_row_ptr, m->d_col, (const T *)m->d_val,
-                           m->format == SPMV_HIP_CSR_SCALAR ? m->d_block_pat : nullptr, m->d_row_map, x, ldx, y, ldy, m->block_map);
+        if constexpr (NV == 1)                 // one vector: gathers in entry order, (x, value) parked
+            hipLaunchKernelGGL((csr_rows_lds_mv_kernel<T, 4, NV, NT>), dim3(blocks_for(m->rows, kWave)), dim3(kWave), 0, st,
+                               m->rows, m->d_row_ptr, m->d_col, (const T *)m->d_val,
+                               m->format == SPMV_HIP_CSR_SCALAR ? m->d_block_pat : nullptr, m->d_row_map, x, ldx, y, ldy, m->block_map);
+        else                                   // gathers by rows; 28 * 64 entries hold a block of 64 rows of up to 28 entries
+            hipLaunchKernelGGL((csr_rows_gather_mv_kernel<T, 28, NV, (NV >= 7 ? 3 : NV >= 5 ? 4 : NV >= 3 ? 5 : 9), NT>),
+                               dim3(blocks_for(m->rows, kWave)), dim3(kWave), 0, st,
+                               m->rows, m->d_row_ptr, m->d_col, (const T *)m->d_val,
+                               m->format == SPMV_HIP_CSR_SCALAR ? m->d_block_pat : nullptr, m->d_row_map, x, ldx, y, ldy, m->block_map);
         break;
     case SPMV_HIP_SELL:
     case SPMV_HIP_SELLP:
@@ -471,14 +574,14 @@ static int launch_block(const spmv_hip_matrix *m, const T *x, int64_t ldx, T *y,
             const dim3 grid(blocks_for(m->nslices, kBlock / kWave)), block(kBlock);
             // the diagonal descriptors pay when at least half the slice columns have one
             const int *diag = m->d_sdiag && m->diag_columns * 2 * kWave >= m->stored ? m->d_sdiag : nullptr;
-            if constexpr (NV % 2 == 0) {
-                if (diag) {                       // two rows per lane, runs of neighbouring distances over the lanes
+            if constexpr (NV >= 2) {
+                if (diag) {                       // runs of neighbouring distances: outer operands over the lanes
                     if (perm)
-                        hipLaunchKernelGGL((sliced64_mv_pair_kernel<T, true, NV, NT>), grid, block, 0, st, m->rows,
+                        hipLaunchKernelGGL((sliced64_mv_rows_kernel<T, true, NV, NT>), grid, block, 0, st, m->rows,
                                            m->columns, m->nslices, m->d_slice_ptr, m->d_row_order, diag, m->d_scol, sv, x,
                                            ldx, y, ldy, m->block_map);
                     else
-                        hipLaunchKernelGGL((sliced64_mv_pair_kernel<T, false, NV, NT>), grid, block, 0, st, m->rows,
+                        hipLaunchKernelGGL((sliced64_mv_rows_kernel<T, false, NV, NT>), grid, block, 0, st, m->rows,
                                            m->columns, m->nslices, m->d_slice_ptr, m->d_row_order, diag, m->d_scol, sv, x,
                                            ldx, y, ldy, m->block_map);
                     break;
@@ -504,7 +607,7 @@ static int launch_block(const spmv_hip_matrix *m, const T *x, int64_t ldx, T *y,
         break;
     }
     case SPMV_HIP_SELL_DFC:
-        hipLaunchKernelGGL((sell_dfc_mv_kernel<T, NV, (NV >= 8 ? 2 : 4), NT>), dim3(blocks_for(m->nslices, kBlock / kWave)),
+        hipLaunchKernelGGL((sell_dfc_mv_kernel<T, NV, (NV >= 5 ? 2 : 4), NT>), dim3(blocks_for(m->nslices, kBlock / kWave)),
                            dim3(kBlock), 0, st, m->rows, m->nslices, m->d_slice_ptr, m->d_sorted_len, m->d_row_order,
                            m->d_scol, (const T *)m->d_sval, x, ldx, y, ldy, m->block_map);
         break;
@@ -521,22 +624,24 @@ static int launch_mult_mv_t(const spmv_hip_matrix *m, int n, const T *x, int64_t
     const bool nt = m->stored * (int64_t)(sizeof(T) + 4) > ((int64_t)512 << 20);
     int v = 0;
     while (v < n) {
-        const int left = n - v;
+        const int took = n - v < 8 ? n - v : 8;
         const T *xv = x + (int64_t)v * ldx;
         T *yv = y + (int64_t)v * ldy;
-        int rc, took;
-        if (left >= 8) {
-            took = 8;
-            rc = nt ? launch_block<T, 8, true>(m, xv, ldx, yv, ldy, st) : launch_block<T, 8, false>(m, xv, ldx, yv, ldy, st);
-        } else if (left >= 4) {
-            took = 4;
-            rc = nt ? launch_block<T, 4, true>(m, xv, ldx, yv, ldy, st) : launch_block<T, 4, false>(m, xv, ldx, yv, ldy, st);
-        } else if (left >= 2) {
-            took = 2;
-            rc = nt ? launch_block<T, 2, true>(m, xv, ldx, yv, ldy, st) : launch_block<T, 2, false>(m, xv, ldx, yv, ldy, st);
-        } else {
-            took = 1;
-            rc = nt ? launch_block<T, 1, true>(m, xv, ldx, yv, ldy, st) : launch_block<T, 1, false>(m, xv, ldx, yv, ldy, st);
+        int rc = 1;
+        switch (took) {
+#define SPMV_MV_BLOCK(N)                                                                                   \
+        case N:                                                                                            \
+            rc = nt ? launch_block<T, N, true>(m, xv, ldx, yv, ldy, st) : launch_block<T, N, false>(m, xv, ldx, yv, ldy, st); \
+            break;
+            SPMV_MV_BLOCK(1)
+            SPMV_MV_BLOCK(2)
+            SPMV_MV_BLOCK(3)
+            SPMV_MV_BLOCK(4)
+            SPMV_MV_BLOCK(5)
+            SPMV_MV_BLOCK(6)
+            SPMV_MV_BLOCK(7)
+            SPMV_MV_BLOCK(8)
+#undef SPMV_MV_BLOCK
         }
         if (rc) return rc;
         v += took;

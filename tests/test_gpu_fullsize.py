@@ -174,6 +174,15 @@ def test_c2_stencil_252_against_the_oracle(orc):
         assert _mult(scalar, x, rows).cpu().numpy().tobytes() == want.tobytes(), ("csr_scalar", v)
     scalar.set_option("block_map", 5)
     assert _mult(scalar, x, rows).cpu().numpy().tobytes() == want.tobytes(), ("csr_scalar", 22, "block_map", 5)
+    # a block of vectors: patterned blocks walked by positions with operands shifted over the lanes, the others by rows
+    X = torch.stack([x, z, 2.0 * x - 3.0 * z, x * z, -x, 0.5 * z, z - x, x + 1.0])
+    Y = torch.full((8, rows), -1.0, dtype=torch.float64, device=DEV)
+    scalar.mult_mv_dev(8, X.data_ptr(), cols, Y.data_ptr(), rows, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert Y[0].cpu().numpy().tobytes() == want.tobytes(), "csr_scalar mult_mv"
+    for k in range(1, 8):
+        assert torch.equal(Y[k], _mult(scalar, X[k], rows)), ("csr_scalar mult_mv", k)
+    del X, Y
     scalar.free()
 
     # ---- the reassociating CSR kernels, every variant that analyze may pick here

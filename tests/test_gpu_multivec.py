@@ -139,6 +139,7 @@ RUN_CASES = {
     "band_13": _band_csr(2100, 13),                     # 27 columns like the 27-point stencil
     "band_4_short_rows": _band_csr(4000, 4, 50, 3),     # padding inside runs
     "band_5": _band_csr(1500, 5),                       # 11 columns: runs and two columns left over
+    "band_15": _band_csr(1300, 15),                     # 31 columns: a patterned 64-row block is longer than one chunk
 }
 
 
@@ -155,10 +156,13 @@ def test_mult_mv_runs_of_neighbouring_diagonals_bitwise(orc, case):
     rows, cols, rp, cj, va = RUN_CASES[case]
     rng = np.random.default_rng(11)
     builders = _builders(rows, cols, rp, cj, va)
-    for name in ("sellp", "sell_1024", "ell"):
+    for name in ("sellp", "sell_1024", "ell", "csr_scalar", "csr_merge", "csr_bal", "csr_vector_pad4"):
         m = builders[name](S.F64)
-        assert m.info.diag_columns * 2 * 64 >= m.info.stored, (case, name)      # the kernel with the runs is the one launched
-        for n in (2, 4, 6, 8, 13):
+        if name == "csr_scalar" and "short" not in case:
+            assert m.info.pattern_blocks * 2 * 64 >= rows, (case, name)         # blocks walked by positions, with runs
+        elif not name.startswith("csr"):
+            assert m.info.diag_columns * 2 * 64 >= m.info.stored, (case, name)  # the kernel with the runs is the one launched
+        for n in (1, 2, 3, 4, 5, 6, 7, 8, 13):
             X = rng.standard_normal((n, cols))
             assert bits_equal(m.mult_mv(X), orc.mult_mv_csr(rp, cj, va, X)), (case, name, n)
         # vectors an odd number of elements apart (pairs of operands and results off their 16-byte alignment)
@@ -173,14 +177,16 @@ def test_mult_mv_runs_of_neighbouring_diagonals_bitwise(orc, case):
         assert np.all(got[:, rows:] == -7.0)
         # x[0] is what the padding of a sliced layout multiplies (sellcs_format.c:167,171; sellp.c:440-452): NaN / inf
         # there, and inside the band -- against the oracle's restatement of the reference's sliced kernels
-        if name != "ell":
+        if name not in ("ell", "csr_vector_pad4"):
             X = rng.standard_normal((4, cols))
             X[0, 0] = np.nan
             X[1, 0] = np.inf
             X[2, cols // 2] = np.inf
             X[3, cols - 1] = np.nan
             with np.errstate(invalid="ignore"):
-                if name == "sellp":
+                if name.startswith("csr"):
+                    want = orc.mult_mv_csr(rp, cj, va, X)                       # no padding in these layouts
+                elif name == "sellp":
                     layout = orc.sliced_ell_from_csr(rp, cj, va, 64)
                     want = np.stack([orc.mult_sliced_ell(layout, X[k])[:rows] for k in range(4)])
                 else:
