@@ -10,7 +10,7 @@
 //   sliced formats of height 64 (SELL-C-sigma, SELLP, ELL)  -> sliced64_mv_kernel; with described slice columns
 //                                                              and two or more vectors sliced64_mv_rows_kernel
 //   sliced formats of other heights                         -> sliced_any_mv_kernel
-//   SELL without padding                                    -> sell_dfc_mv_kernel
+//   SELL without padding                                    -> sell_dfc_mv_kernel (full columns as in the rows kernel)
 //   CSR, merge-path CSR, balanced CSR (all hold plain CSR)  -> csr_rows_gather_mv_kernel (one vector:
 //                                                              csr_rows_lds_mv_kernel)
 
@@ -267,12 +267,18 @@ __global__ __launch_bounds__(kBlock) void sliced_any_mv_kernel(int rows, int hei
 
 // SELL-C-sigma without padding: column j of a slice holds the rows longer than j, which are lanes
 // 0..active-1 because the slice's rows are sorted by length (reference sellcs_format.c:53-136).
-// The start of each column is carried as a wave-uniform counter.
+// The start of each column is carried as a wave-uniform counter.  The columns below the slice's shortest row hold
+// all 64 lanes: with descriptors (sdiag, one int per column from vop_ptr[s] on; may be null) and two or more
+// vectors they are walked like the columns of sliced64_mv_rows_kernel -- described columns compute their indices,
+// runs of three neighbouring distances over 64 neighbouring rows gather only the middle column.  There is no
+// padding in this layout, so every lane of a described column holds a real entry.
 template <typename T, int NV, int U, bool NT>
 __global__ __launch_bounds__(kBlock) void sell_dfc_mv_kernel(int rows, int nslices,
                                                              const int64_t *__restrict__ slice_ptr,
                                                              const int *__restrict__ sorted_len,
                                                              const int *__restrict__ row_order,
+                                                             const int64_t *__restrict__ vop_ptr,
+                                                             const int *__restrict__ sdiag,
                                                              const int *__restrict__ scol,
                                                              const T *__restrict__ sval,
                                                              const T *__restrict__ x, int64_t ldx,
@@ -291,7 +297,76 @@ __global__ __launch_bounds__(kBlock) void sell_dfc_mv_kernel(int rows, int nslic
     T acc[NV];
 #pragma unroll
     for (int k = 0; k < NV; k++) acc[k] = 0;
-    for (int j0 = 0; j0 < width; j0 += U) {
+    int first = 0;                                           // columns before it are done
+    if (NV >= 2 && sdiag) {
+        const int shortest = __builtin_amdgcn_readlane(len, kWave - 1);       // columns below it hold all 64 lanes
+        const int row = r < rows ? row_order[r] : 0;
+        const int row0 = __builtin_amdgcn_readfirstlane(row);
+        const bool in_order = __ballot(r >= rows || row != row0 + lane) == 0;
+        const int *dg = sdiag + vop_ptr[s];
+        auto runs = [&](const int *dmid, auto count) {
+            constexpr int R = decltype(count)::value;
+            T vv[R][3], mid[R][NV], beside[R];
+#pragma unroll
+            for (int t = 0; t < R; t++) {
+#pragma unroll
+                for (int u = 0; u < 3; u++) vv[t][u] = stream_load<T, NT>(v + run + (3 * t + u) * kWave);
+#pragma unroll
+                for (int k = 0; k < NV; k++) mid[t][k] = x[k * ldx + row + dmid[t]];
+                beside[t] = 0;
+                if (lane < 2 * NV) beside[t] = x[(lane >> 1) * ldx + row0 + ((lane & 1) ? kWave + dmid[t] : dmid[t] - 1)];
+            }
+#pragma unroll
+            for (int t = 0; t < R; t++)
+#pragma unroll
+                for (int k = 0; k < NV; k++) {
+                    const T outer = __shfl(beside[t], 2 * k + (lane == kWave - 1 ? 1 : 0));
+                    const T lo = neighbour_lane<true>(mid[t][k], outer), hi = neighbour_lane<false>(mid[t][k], outer);
+                    acc[k] = fma_t(lo, vv[t][0], acc[k]);
+                    acc[k] = fma_t(mid[t][k], vv[t][1], acc[k]);
+                    acc[k] = fma_t(hi, vv[t][2], acc[k]);
+                }
+            run += 3 * R * kWave;
+        };
+        constexpr int RB = NV >= 5 ? 2 : 3;
+        int j = 0;
+        while (j < shortest) {
+            int d[3 * RB];
+            int nr = 0;
+#pragma unroll
+            for (int t = 0; t < RB; t++) {
+                if (nr == t && j + 3 * (t + 1) <= shortest) {
+                    d[3 * t] = __builtin_amdgcn_readfirstlane(dg[j + 3 * t]);
+                    d[3 * t + 1] = __builtin_amdgcn_readfirstlane(dg[j + 3 * t + 1]);
+                    d[3 * t + 2] = __builtin_amdgcn_readfirstlane(dg[j + 3 * t + 2]);
+                    if (in_order && d[3 * t] != INT_MIN && d[3 * t + 1] == d[3 * t] + 1 && d[3 * t + 2] == d[3 * t] + 2) nr = t + 1;
+                }
+            }
+            if (nr == RB) {
+                int dmid[RB];
+#pragma unroll
+                for (int t = 0; t < RB; t++) dmid[t] = d[3 * t + 1];
+                runs(dmid, std::integral_constant<int, RB>{});
+                j += 3 * RB;
+            } else if (nr >= 1) {
+                runs(&d[1], std::integral_constant<int, 1>{});
+                j += 3;
+            } else {
+                const int dj = __builtin_amdgcn_readfirstlane(dg[j]);
+                const int cc = dj != INT_MIN ? row + dj : stream_load<int, NT>(c + run);
+                const T vv = stream_load<T, NT>(v + run);
+                T xx[NV];
+#pragma unroll
+                for (int k = 0; k < NV; k++) xx[k] = x[k * ldx + cc];
+#pragma unroll
+                for (int k = 0; k < NV; k++) acc[k] = fma_t(xx[k], vv, acc[k]);
+                run += kWave;
+                j += 1;
+            }
+        }
+        first = shortest;
+    }
+    for (int j0 = first; j0 < width; j0 += U) {
         int off[U], cc[U];
         T vv[U];
 #pragma unroll
@@ -609,6 +684,7 @@ static int launch_block(const spmv_hip_matrix *m, const T *x, int64_t ldx, T *y,
     case SPMV_HIP_SELL_DFC:
         hipLaunchKernelGGL((sell_dfc_mv_kernel<T, NV, (NV >= 5 ? 2 : 4), NT>), dim3(blocks_for(m->nslices, kBlock / kWave)),
                            dim3(kBlock), 0, st, m->rows, m->nslices, m->d_slice_ptr, m->d_sorted_len, m->d_row_order,
+                           m->d_vop_ptr, m->d_vop_ptr && m->diag_columns * 2 >= m->vops ? m->d_sdiag : nullptr,
                            m->d_scol, (const T *)m->d_sval, x, ldx, y, ldy, m->block_map);
         break;
     default: set_error("unknown format %d", m->format); return 1;

@@ -156,10 +156,12 @@ def test_mult_mv_runs_of_neighbouring_diagonals_bitwise(orc, case):
     rows, cols, rp, cj, va = RUN_CASES[case]
     rng = np.random.default_rng(11)
     builders = _builders(rows, cols, rp, cj, va)
-    for name in ("sellp", "sell_1024", "ell", "csr_scalar", "csr_merge", "csr_bal", "csr_vector_pad4"):
+    for name in ("sellp", "sell_1024", "ell", "sell_dfc", "csr_scalar", "csr_merge", "csr_bal", "csr_vector_pad4"):
         m = builders[name](S.F64)
         if name == "csr_scalar" and "short" not in case:
             assert m.info.pattern_blocks * 2 * 64 >= rows, (case, name)         # blocks walked by positions, with runs
+        elif name == "sell_dfc":
+            assert m.info.diag_columns > 0, (case, name)
         elif not name.startswith("csr"):
             assert m.info.diag_columns * 2 * 64 >= m.info.stored, (case, name)  # the kernel with the runs is the one launched
         for n in (1, 2, 3, 4, 5, 6, 7, 8, 13):
@@ -184,7 +186,7 @@ def test_mult_mv_runs_of_neighbouring_diagonals_bitwise(orc, case):
             X[2, cols // 2] = np.inf
             X[3, cols - 1] = np.nan
             with np.errstate(invalid="ignore"):
-                if name.startswith("csr"):
+                if name.startswith("csr") or name == "sell_dfc":
                     want = orc.mult_mv_csr(rp, cj, va, X)                       # no padding in these layouts
                 elif name == "sellp":
                     layout = orc.sliced_ell_from_csr(rp, cj, va, 64)
