@@ -84,8 +84,9 @@ typedef struct spmv_hip_info {
     int     hot_columns;  /* option "hot_columns": 0 off, 1 columns relabeled by reference count, 2 dealt over the XCDs */
     int64_t diag_columns; /* sliced formats of height 64: slice columns (64 entries each) whose entries all sit at
                              one distance from the diagonal; the variants >= 16 do not read their indices */
-    int     pattern_blocks; /* CSR_SCALAR: blocks of 64 rows that repeat one pattern of distances from the
-                             diagonal; the variants >= 16 read one row's indices for each */
+    int     pattern_blocks; /* CSR-based handles: blocks of 64 rows that repeat one pattern of distances from the
+                             diagonal; CSR_SCALAR variants >= 16 read one row's indices for each, and the products
+                             with a block of vectors walk them by positions */
     int     hot_variant;  /* with hot_columns 2: tile kernel of the copy split by column group (option "hot_variant") */
     int     block_map;    /* option "block_map": how workgroups are dealt over the matrix (0 an eighth per XCD, K runs of K) */
 } spmv_hip_info;

@@ -150,10 +150,12 @@ static int finish_from_device_csr(spmv_hip_matrix *m, int64_t p0, int64_t p1, bo
     // (stencil 252^3 fp32 +9 %, FEM stand-in +6 %; the 1000^2 Laplacian with its 5 M entries loses 12 %)
     case SPMV_HIP_CSR_MERGE:
         if (normalize_tile_param(p0, m->dtype == SPMV_HIP_F32 && m->stored >= (1 << 25) ? 1024 : 512, &m->items_per_tile)) return 1;
-        return build_merge_tiles(m, st);
+        if (build_merge_tiles(m, st)) return 1;
+        return build_block_patterns(m, st);                  // for the products with a block of vectors
     case SPMV_HIP_CSR_BAL:
         if (normalize_tile_param(p0, m->dtype == SPMV_HIP_F32 && m->stored >= (1 << 25) ? 1024 : 512, &m->items_per_tile)) return 1;
-        return build_bal_tiles(m, st);
+        if (build_bal_tiles(m, st)) return 1;
+        return build_block_patterns(m, st);
     case SPMV_HIP_SELL:
     case SPMV_HIP_SELLP:
     case SPMV_HIP_ELL: {

@@ -633,12 +633,12 @@ static int launch_block(const spmv_hip_matrix *m, const T *x, int64_t ldx, T *y,
         if constexpr (NV == 1)                 // one vector: gathers in entry order, (x, value) parked
             hipLaunchKernelGGL((csr_rows_lds_mv_kernel<T, 4, NV, NT>), dim3(blocks_for(m->rows, kWave)), dim3(kWave), 0, st,
                                m->rows, m->d_row_ptr, m->d_col, (const T *)m->d_val,
-                               m->format == SPMV_HIP_CSR_SCALAR ? m->d_block_pat : nullptr, m->d_row_map, x, ldx, y, ldy, m->block_map);
+                               m->d_block_pat, m->d_row_map, x, ldx, y, ldy, m->block_map);
         else                                   // gathers by rows; 28 * 64 entries hold a block of 64 rows of up to 28 entries
             hipLaunchKernelGGL((csr_rows_gather_mv_kernel<T, 28, NV, (NV >= 7 ? 3 : NV >= 5 ? 4 : NV >= 3 ? 5 : 9), NT>),
                                dim3(blocks_for(m->rows, kWave)), dim3(kWave), 0, st,
                                m->rows, m->d_row_ptr, m->d_col, (const T *)m->d_val,
-                               m->format == SPMV_HIP_CSR_SCALAR ? m->d_block_pat : nullptr, m->d_row_map, x, ldx, y, ldy, m->block_map);
+                               m->d_block_pat, m->d_row_map, x, ldx, y, ldy, m->block_map);
         break;
     case SPMV_HIP_SELL:
     case SPMV_HIP_SELLP:

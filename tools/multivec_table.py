@@ -17,7 +17,8 @@ import spmv_amd as S  # noqa: E402
 from spmv_amd import generators as G  # noqa: E402
 from spmv_amd.matrix import Matrix  # noqa: E402
 
-FORMATS = {"csr_scalar": (S.CSR_SCALAR, 0, 0), "sell": (S.SELL, 64, 1024), "sell_dfc": (S.SELL_DFC, 64, 1024),
+FORMATS = {"csr_scalar": (S.CSR_SCALAR, 0, 0), "csr_merge": (S.CSR_MERGE, 0, 0), "csr_bal": (S.CSR_BAL, 0, 0),
+           "csr_vector": (S.CSR_VECTOR, 0, 0), "sell": (S.SELL, 64, 1024), "sell_dfc": (S.SELL_DFC, 64, 1024),
            "sellp": (S.SELLP, 0, 0)}
 
 
