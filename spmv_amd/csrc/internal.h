@@ -68,7 +68,7 @@ struct spmv_hip_matrix {
     void *d_val = nullptr;
     int lanes_per_row = 0;
     const int *d_row_map = nullptr; // CSR_SCALAR / CSR_VECTOR: matrix row k writes y[row_map[k]] (caller's array)
-    unsigned char *d_block_pat = nullptr; // CSR_SCALAR: per block of 64 rows, the common row length when all its
+    unsigned char *d_block_pat = nullptr; // CSR-based formats: per block of 64 rows, the common row length when all its
                                           // rows repeat one pattern of distances from the diagonal, else 0
     int pat_blocks = 0;            // how many blocks do
     int variant = 0;               // kernel variant inside the format (spmv_hip_set_option "variant")

@@ -36,7 +36,8 @@ STEPS, WARMUP = 10, 3
 SWEEP_SELL_VARIANTS = "18,22,28,29,30,31,4,12,24,26"
 SWEEP_MAPS = "0,1,2,3,4,5,8"
 SHORT = (("wave_tile", "tile"), ("tile_fixup", "fixup"), ("permute_x", "permute_x"), ("sum_partials", "sum_partials"))
-PRODUCT_KERNELS = re.compile(r"spmv::(sliced|csr_|wave_tile|tile_fixup|permute_x|sum_partials|sell_dfc)")
+# (csr_block_pattern_kernel belongs to the creators: every CSR-based handle scans its row blocks once)
+PRODUCT_KERNELS = re.compile(r"spmv::(sliced|csr_(?!block_pattern)|wave_tile|tile_fixup|permute_x|sum_partials|sell_dfc)")
 
 
 def run(cmd, log, limit):
