@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--p0", default="0", help="comma list of p0 values (lanes / tile size / slice height)")
     ap.add_argument("--variants", default="0")
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--in-a-row", action="store_true", help="also time the same number of products queued between one event pair")
     ap.add_argument("--block-maps", default="", help="comma list of option block_map values to time every variant under (0, 1)")
     ap.add_argument("--hot", type=int, default=0, help="option hot_columns of CSR-based handles (0, 1, 2)")
     ap.add_argument("--hot-variants", default="", help="with --hot 2: comma list of tile kernels of the stacked matrix (0, 1, 3, 4)")
@@ -86,6 +87,15 @@ def main():
                 a.record(); m.mult_dev(x.data_ptr(), y.data_ptr(), st); b.record()
             torch.cuda.synchronize()
             ms = sorted(a.elapsed_time(b) for a, b in ev)
+            in_a_row = None
+            if args.in_a_row:           # the same launches queued between one event pair (products of a few microseconds:
+                a, b = ev[0]            # an event pair around a launch on an empty queue reads ~2 us more than the kernel)
+                a.record()
+                for _ in range(args.steps):
+                    m.mult_dev(x.data_ptr(), y.data_ptr(), st)
+                b.record()
+                torch.cuda.synchronize()
+                in_a_row = a.elapsed_time(b) / args.steps
             if y0 is None:
                 y0 = y.clone()
             err = float(torch.linalg.vector_norm(y - y0) / torch.linalg.vector_norm(y0))
@@ -96,7 +106,7 @@ def main():
             info = m.info
             print("RESULT " + json.dumps({"format": args.format, "matrix": args.matrix, "n": args.n, "dtype": args.dtype,
                                           "hot": args.hot, "hot_variant": info.hot_variant, "variant": info.variant, "block_map": info.block_map, "lanes_per_row": info.lanes_per_row,
-                                          "median_ms": med, "min_ms": ms[0], "rows": rows, "cols": cols, "nnz": nnz,
+                                          "median_ms": med, "min_ms": ms[0], "in_a_row_ms": in_a_row, "rows": rows, "cols": cols, "nnz": nnz,
                                           "stored": info.stored, "b_alg": b_alg}), flush=True)
         m.free()
 
