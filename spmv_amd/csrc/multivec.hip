@@ -147,7 +147,19 @@ __global__ __launch_bounds__(kBlock) void sliced64_mv_rows_kernel(int rows, int 
     const int r = s * kWave + lane;
     const int row = PERM ? row_order[min(r, rows - 1)] : min(r, rows - 1);
     const int row0 = __builtin_amdgcn_readfirstlane(row);
-    const bool in_order = __ballot(r >= rows || row != row0 + lane) == 0;
+    // where the rows stop being neighbours: nowhere (in_order), or at ONE place between lanes gap_at and gap_at + 1 --
+    // the hole the window sort leaves where it took a grid line's two end rows out (PERM only)
+    const int next_row = __shfl_down(row, 1);
+    const uint64_t jumps = __ballot(lane < kWave - 1 && next_row != row + 1);
+    const bool all_rows = s * kWave + kWave <= rows;
+    const bool in_order = all_rows && jumps == 0;
+    const bool one_gap = PERM && all_rows && __popcll(jumps) == 1;
+    const int gap_at = one_gap ? __ffsll((unsigned long long)jumps) - 1 : -2;
+    const bool gap_ok = one_gap && gap_at >= 1 && gap_at + 1 <= kWave - 2;          // lanes 0, gap_at, gap_at + 1, 63 differ
+    const int row_before_gap = gap_ok ? __builtin_amdgcn_readlane(row, gap_at) : 0;
+    const int row_after_gap = gap_ok ? __builtin_amdgcn_readlane(row, gap_at + 1) : 0;
+    const int row_last = __builtin_amdgcn_readlane(row, kWave - 1);
+    const int lowest = gap_ok ? min(row0, row_after_gap) : row0, highest = gap_ok ? max(row_before_gap, row_last) : row_last;
     const int *dg = sdiag + (base >> 6);
     const int last = max(cols - 1, 0);
     T acc[NV];
@@ -165,8 +177,17 @@ __global__ __launch_bounds__(kBlock) void sliced64_mv_rows_kernel(int rows, int 
         for (int k = 0; k < NV; k++) acc[k] = fma_t(xx[k], vv, acc[k]);
     };
     auto is_run = [&](int d0, int d1, int d2) {
-        return in_order && d0 != INT_MIN && d1 == d0 + 1 && d2 == d0 + 2 && row0 + d0 >= 0 && row0 + kWave - 1 + d2 <= last;
+        return (in_order || gap_ok) && d0 != INT_MIN && d1 == d0 + 1 && d2 == d0 + 2 && lowest + d0 >= 0 && highest + d2 <= last;
     };
+    // the elements beside the windows, for all vectors in one load: lane 2v before the first row's, lane 2v + 1 after
+    // the last row's; with a gap, lane 2 NV + 2v after the window of the row before it and lane 2 NV + 2v + 1 before
+    // the window of the row after it
+    const int which = lane >= 2 * NV;
+    const int beside_row = (lane & 1) ? (which ? row_after_gap : row_last) : (which ? row_before_gap : row0);
+    const int beside_lanes = gap_ok ? 4 * NV : 2 * NV;
+    const int beside_vec = (lane - (which ? 2 * NV : 0)) >> 1;
+    // where each lane finds the outer operand it cannot get from its neighbour
+    const int outer_from = lane == 0 ? 0 : lane == kWave - 1 ? 1 : lane == gap_at ? 2 * NV : lane == gap_at + 1 ? 2 * NV + 1 : 0;
     auto runs = [&](int jj, const int *dmid, auto count) {
         constexpr int R = decltype(count)::value;
         T vv[R][3], mid[R][NV], beside[R];
@@ -177,7 +198,9 @@ __global__ __launch_bounds__(kBlock) void sliced64_mv_rows_kernel(int rows, int 
 #pragma unroll
             for (int k = 0; k < NV; k++) mid[t][k] = x[k * ldx + row + dmid[t]];
             beside[t] = 0;
-            if (lane < 2 * NV) beside[t] = x[(lane >> 1) * ldx + row0 + ((lane & 1) ? kWave + dmid[t] : dmid[t] - 1)];
+            // lanes 2v + 1 and 2 NV + 2v take the element after a window (d + 1), lanes 2v and 2 NV + 2v + 1 the one before
+            if (lane < beside_lanes)
+                beside[t] = x[beside_vec * ldx + beside_row + dmid[t] + (((lane & 1) != which) ? 1 : -1)];
         }
         bool zero = false;
 #pragma unroll
@@ -189,8 +212,10 @@ __global__ __launch_bounds__(kBlock) void sliced64_mv_rows_kernel(int rows, int 
             for (int t = 0; t < R; t++)
 #pragma unroll
                 for (int k = 0; k < NV; k++) {
-                    const T outer = __shfl(beside[t], 2 * k + (lane == kWave - 1 ? 1 : 0));
-                    const T lo = neighbour_lane<true>(mid[t][k], outer), hi = neighbour_lane<false>(mid[t][k], outer);
+                    const T outer = __shfl(beside[t], 2 * k + outer_from);
+                    T lo = neighbour_lane<true>(mid[t][k], outer), hi = neighbour_lane<false>(mid[t][k], outer);
+                    if (lane == gap_at + 1) lo = outer;
+                    if (lane == gap_at) hi = outer;
                     const T x0 = CHECK ? x[k * ldx] : (T)0;
                     acc[k] = fma_t(CHECK && vv[t][0] == (T)0 ? x0 : lo, vv[t][0], acc[k]);
                     acc[k] = fma_t(CHECK && vv[t][1] == (T)0 ? x0 : mid[t][k], vv[t][1], acc[k]);
