@@ -744,19 +744,16 @@ static int analyze_impl(spmv_hip_matrix *m, int reps, float *best_ms_out)
             return 0;
         }
     }
-    // one warm-up launch, then `reps` timed ones of the handle as it is set
+    // one warm-up launch, then `reps` launches of the handle as it is set, queued one after the other between one pair
+    // of events (an event pair around every launch would add the start of a launch on an empty queue to each: 2 us,
+    // a sixth of a product of a small matrix, and noise of that size)
     auto time_current = [&](float *total) {
         if (launch_mult(m, m->d_x, m->d_y, nullptr)) return 1;
-        *total = 0;
-        for (int r = 0; r < reps; r++) {
-            if (hipEventRecord(e0, nullptr) != hipSuccess || launch_mult(m, m->d_x, m->d_y, nullptr) ||
-                hipEventRecord(e1, nullptr) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)
-                return 1;
-            float ms = 0;
-            if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return 1;
-            *total += ms;
-        }
-        return 0;
+        if (hipEventRecord(e0, nullptr) != hipSuccess) return 1;
+        for (int r = 0; r < reps; r++)
+            if (launch_mult(m, m->d_x, m->d_y, nullptr)) return 1;
+        if (hipEventRecord(e1, nullptr) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return 1;
+        return hipEventElapsedTime(total, e0, e1) != hipSuccess ? 1 : 0;
     };
     bool first = true;
     auto pick_variant = [&]() {
