@@ -123,8 +123,10 @@ template <bool UP, typename T> __device__ __forceinline__ T neighbour_lane(T c, 
 // grid stencil), lane l's operands are x[row + d - 1 .. row + d + 1] = the middle operands of lanes l-1, l, l+1:
 // every vector gathers the middle column once with all lanes, the outer two come over the lanes (DPP wave shifts),
 // and the element before lane 0's and after lane 63's window come for ALL vectors in one load (lane 2v: before,
-// lane 2v + 1: after, of vector v).  Two or three such runs are in flight together.  Same operands, same order of
-// the sums: the bits of sliced64_mv_kernel.  A zero value in a described column is padding and multiplies x_v[0]
+// lane 2v + 1: after, of vector v).  A slice whose rows are neighbours except at ONE place (the window sort of
+// SELL-C-sigma takes the two end rows of a grid line out of the interior rows) is walked the same way: the two lanes
+// beside the gap get their missing operand from two more lanes per vector of that one load.  Two or three such runs
+// are in flight together.  Same operands, same order of the sums: the bits of sliced64_mv_kernel.  A zero value in a described column is padding and multiplies x_v[0]
 // (sellcs_format.c:167,171), as there.
 template <typename T, bool PERM, int NV, bool NT>
 __global__ __launch_bounds__(kBlock) void sliced64_mv_rows_kernel(int rows, int cols, int nslices,
