@@ -430,7 +430,11 @@ int spmv_hip_scale_dev(int n, const void *d_y, void *d_x, int dtype, const doubl
  *    SELL-64-1024 fp64 on that matrix 0.803 ms with 0, 0.794 with 1, 0.761 with
  *    5.  The column-split
  *    copy behind "hot_columns" = 2 always keeps 0 (an XCD has to stay with its
- *    column group).
+ *    column group).  spmv_hip_mult_mv with two or more vectors on a window-sorted
+ *    handle (SELL-C-sigma with or without padding) uses the value only if it is
+ *    an odd K >= 3, and 5 otherwise: the short rows of every window of 1024
+ *    rows sit in every 4th workgroup, and any other dealing hands those
+ *    workgroups to one shader engine of each XCD.
  *  "exact_order" = 1: spmv_hip_analyze may only pick kernel variants that leave
  *    the bits of y as they are under the current setting, so that tuning noise
  *    cannot change results from run to run: for the sliced formats the variants

@@ -116,6 +116,49 @@ template <bool UP, typename T> __device__ __forceinline__ T neighbour_lane(T c, 
     }
 }
 
+// How the 64 rows of a wave (lane = row) lie to each other, for the walk of runs below: neighbours in ascending order
+// everywhere (gap_at = -2), or everywhere except between the lanes gap_at and gap_at + 1 -- what the window sort of
+// SELL-C-sigma leaves where it took the two end rows of a grid line out of the interior rows.  In a run of three
+// columns at the distances d-1, d, d+1 lane l's outer operands are the middle operands x[row + d] of lanes l-1 and
+// l+1; the lanes without such a neighbour (0, 63, and the two beside a gap) find theirs in ONE load that serves all
+// NV vectors: lane 2v holds the element before lane 0's window and lane 2v + 1 the one after lane 63's, of vector v;
+// with a gap, lane 2 NV + 2v the one after the window of lane gap_at and lane 2 NV + 2v + 1 the one before the
+// window of lane gap_at + 1.
+struct row_neighbours {
+    bool usable;         // the walk of runs applies
+    int gap_at;
+    int lowest, highest; // smallest and largest row of the wave
+    int beside_lanes;    // lanes that take part in the load: 2 NV, with a gap 4 NV
+    int beside_vec;      // this lane's vector in it,
+    int beside_row;      // the row whose window it sits beside,
+    int beside_step;     // and on which side: x[beside_vec * ldx + beside_row + d + beside_step]
+    int outer_from;      // lane 2v + outer_from of that load holds the outer operand this lane cannot get from a neighbour
+};
+
+template <int NV> __device__ __forceinline__ row_neighbours neighbours_of(int row, int lane, bool all_rows, bool may_gap)
+{
+    row_neighbours n;
+    const int next_row = __shfl_down(row, 1);
+    const uint64_t jumps = __ballot(lane < kWave - 1 && next_row != row + 1);
+    const bool one_gap = may_gap && all_rows && __popcll(jumps) == 1;
+    const int at = one_gap ? __ffsll((unsigned long long)jumps) - 1 : -2;
+    const bool gap = one_gap && at >= 1 && at + 1 <= kWave - 2;      // the lanes 0, at, at + 1, 63 are four lanes
+    n.usable = all_rows && (jumps == 0 || gap);
+    n.gap_at = gap ? at : -2;
+    const int row0 = __builtin_amdgcn_readfirstlane(row), row_last = __builtin_amdgcn_readlane(row, kWave - 1);
+    const int before_gap = gap ? __builtin_amdgcn_readlane(row, at) : row0;
+    const int after_gap = gap ? __builtin_amdgcn_readlane(row, at + 1) : row_last;
+    n.lowest = min(row0, after_gap);
+    n.highest = max(before_gap, row_last);
+    const int second = lane >= 2 * NV;                               // the part of the load that serves the gap
+    n.beside_lanes = gap ? 4 * NV : 2 * NV;
+    n.beside_vec = (lane - (second ? 2 * NV : 0)) >> 1;
+    n.beside_row = (lane & 1) ? (second ? after_gap : row_last) : (second ? before_gap : row0);
+    n.beside_step = ((lane & 1) != second) ? 1 : -1;
+    n.outer_from = lane == 0 ? 0 : lane == kWave - 1 ? 1 : lane == n.gap_at ? 2 * NV : lane == n.gap_at + 1 ? 2 * NV + 1 : 0;
+    return n;
+}
+
 // The same product for matrices with described slice columns (sdiag not null) and two or more vectors.  With several
 // vectors the product waits on its many small gathers; what a gather costs the CU's texture addresser hardly depends
 // on its active lanes or bytes, so the count of vector memory instructions is what to cut.  Where a slice's 64 rows
@@ -148,20 +191,7 @@ __global__ __launch_bounds__(kBlock) void sliced64_mv_rows_kernel(int rows, int 
     const int *c = scol + base + lane;
     const int r = s * kWave + lane;
     const int row = PERM ? row_order[min(r, rows - 1)] : min(r, rows - 1);
-    const int row0 = __builtin_amdgcn_readfirstlane(row);
-    // where the rows stop being neighbours: nowhere (in_order), or at ONE place between lanes gap_at and gap_at + 1 --
-    // the hole the window sort leaves where it took a grid line's two end rows out (PERM only)
-    const int next_row = __shfl_down(row, 1);
-    const uint64_t jumps = __ballot(lane < kWave - 1 && next_row != row + 1);
-    const bool all_rows = s * kWave + kWave <= rows;
-    const bool in_order = all_rows && jumps == 0;
-    const bool one_gap = PERM && all_rows && __popcll(jumps) == 1;
-    const int gap_at = one_gap ? __ffsll((unsigned long long)jumps) - 1 : -2;
-    const bool gap_ok = one_gap && gap_at >= 1 && gap_at + 1 <= kWave - 2;          // lanes 0, gap_at, gap_at + 1, 63 differ
-    const int row_before_gap = gap_ok ? __builtin_amdgcn_readlane(row, gap_at) : 0;
-    const int row_after_gap = gap_ok ? __builtin_amdgcn_readlane(row, gap_at + 1) : 0;
-    const int row_last = __builtin_amdgcn_readlane(row, kWave - 1);
-    const int lowest = gap_ok ? min(row0, row_after_gap) : row0, highest = gap_ok ? max(row_before_gap, row_last) : row_last;
+    const row_neighbours nb = neighbours_of<NV>(row, lane, s * kWave + kWave <= rows, PERM);
     const int *dg = sdiag + (base >> 6);
     const int last = max(cols - 1, 0);
     T acc[NV];
@@ -178,18 +208,10 @@ __global__ __launch_bounds__(kBlock) void sliced64_mv_rows_kernel(int rows, int 
 #pragma unroll
         for (int k = 0; k < NV; k++) acc[k] = fma_t(xx[k], vv, acc[k]);
     };
+    // a run whose operands all lie inside x (a padding lane of a described column may point anywhere)
     auto is_run = [&](int d0, int d1, int d2) {
-        return (in_order || gap_ok) && d0 != INT_MIN && d1 == d0 + 1 && d2 == d0 + 2 && lowest + d0 >= 0 && highest + d2 <= last;
+        return nb.usable && d0 != INT_MIN && d1 == d0 + 1 && d2 == d0 + 2 && nb.lowest + d0 >= 0 && nb.highest + d2 <= last;
     };
-    // the elements beside the windows, for all vectors in one load: lane 2v before the first row's, lane 2v + 1 after
-    // the last row's; with a gap, lane 2 NV + 2v after the window of the row before it and lane 2 NV + 2v + 1 before
-    // the window of the row after it
-    const int which = lane >= 2 * NV;
-    const int beside_row = (lane & 1) ? (which ? row_after_gap : row_last) : (which ? row_before_gap : row0);
-    const int beside_lanes = gap_ok ? 4 * NV : 2 * NV;
-    const int beside_vec = (lane - (which ? 2 * NV : 0)) >> 1;
-    // where each lane finds the outer operand it cannot get from its neighbour
-    const int outer_from = lane == 0 ? 0 : lane == kWave - 1 ? 1 : lane == gap_at ? 2 * NV : lane == gap_at + 1 ? 2 * NV + 1 : 0;
     auto runs = [&](int jj, const int *dmid, auto count) {
         constexpr int R = decltype(count)::value;
         T vv[R][3], mid[R][NV], beside[R];
@@ -200,9 +222,7 @@ __global__ __launch_bounds__(kBlock) void sliced64_mv_rows_kernel(int rows, int 
 #pragma unroll
             for (int k = 0; k < NV; k++) mid[t][k] = x[k * ldx + row + dmid[t]];
             beside[t] = 0;
-            // lanes 2v + 1 and 2 NV + 2v take the element after a window (d + 1), lanes 2v and 2 NV + 2v + 1 the one before
-            if (lane < beside_lanes)
-                beside[t] = x[beside_vec * ldx + beside_row + dmid[t] + (((lane & 1) != which) ? 1 : -1)];
+            if (lane < nb.beside_lanes) beside[t] = x[nb.beside_vec * ldx + nb.beside_row + dmid[t] + nb.beside_step];
         }
         bool zero = false;
 #pragma unroll
@@ -214,10 +234,10 @@ __global__ __launch_bounds__(kBlock) void sliced64_mv_rows_kernel(int rows, int 
             for (int t = 0; t < R; t++)
 #pragma unroll
                 for (int k = 0; k < NV; k++) {
-                    const T outer = __shfl(beside[t], 2 * k + outer_from);
+                    const T outer = __shfl(beside[t], 2 * k + nb.outer_from);
                     T lo = neighbour_lane<true>(mid[t][k], outer), hi = neighbour_lane<false>(mid[t][k], outer);
-                    if (lane == gap_at + 1) lo = outer;
-                    if (lane == gap_at) hi = outer;
+                    if (lane == nb.gap_at + 1) lo = outer;
+                    if (lane == nb.gap_at) hi = outer;
                     const T x0 = CHECK ? x[k * ldx] : (T)0;
                     acc[k] = fma_t(CHECK && vv[t][0] == (T)0 ? x0 : lo, vv[t][0], acc[k]);
                     acc[k] = fma_t(CHECK && vv[t][1] == (T)0 ? x0 : mid[t][k], vv[t][1], acc[k]);
@@ -328,8 +348,7 @@ __global__ __launch_bounds__(kBlock) void sell_dfc_mv_kernel(int rows, int nslic
     if (NV >= 2 && sdiag) {
         const int shortest = __builtin_amdgcn_readlane(len, kWave - 1);       // columns below it hold all 64 lanes
         const int row = r < rows ? row_order[r] : 0;
-        const int row0 = __builtin_amdgcn_readfirstlane(row);
-        const bool in_order = __ballot(r >= rows || row != row0 + lane) == 0;
+        const row_neighbours nb = neighbours_of<NV>(row, lane, s * kWave + kWave <= rows, true);
         const int *dg = sdiag + vop_ptr[s];
         auto runs = [&](const int *dmid, auto count) {
             constexpr int R = decltype(count)::value;
@@ -341,14 +360,16 @@ __global__ __launch_bounds__(kBlock) void sell_dfc_mv_kernel(int rows, int nslic
 #pragma unroll
                 for (int k = 0; k < NV; k++) mid[t][k] = x[k * ldx + row + dmid[t]];
                 beside[t] = 0;
-                if (lane < 2 * NV) beside[t] = x[(lane >> 1) * ldx + row0 + ((lane & 1) ? kWave + dmid[t] : dmid[t] - 1)];
+                if (lane < nb.beside_lanes) beside[t] = x[nb.beside_vec * ldx + nb.beside_row + dmid[t] + nb.beside_step];
             }
 #pragma unroll
             for (int t = 0; t < R; t++)
 #pragma unroll
                 for (int k = 0; k < NV; k++) {
-                    const T outer = __shfl(beside[t], 2 * k + (lane == kWave - 1 ? 1 : 0));
-                    const T lo = neighbour_lane<true>(mid[t][k], outer), hi = neighbour_lane<false>(mid[t][k], outer);
+                    const T outer = __shfl(beside[t], 2 * k + nb.outer_from);
+                    T lo = neighbour_lane<true>(mid[t][k], outer), hi = neighbour_lane<false>(mid[t][k], outer);
+                    if (lane == nb.gap_at + 1) lo = outer;
+                    if (lane == nb.gap_at) hi = outer;
                     acc[k] = fma_t(lo, vv[t][0], acc[k]);
                     acc[k] = fma_t(mid[t][k], vv[t][1], acc[k]);
                     acc[k] = fma_t(hi, vv[t][2], acc[k]);
@@ -366,7 +387,7 @@ __global__ __launch_bounds__(kBlock) void sell_dfc_mv_kernel(int rows, int nslic
                     d[3 * t] = __builtin_amdgcn_readfirstlane(dg[j + 3 * t]);
                     d[3 * t + 1] = __builtin_amdgcn_readfirstlane(dg[j + 3 * t + 1]);
                     d[3 * t + 2] = __builtin_amdgcn_readfirstlane(dg[j + 3 * t + 2]);
-                    if (in_order && d[3 * t] != INT_MIN && d[3 * t + 1] == d[3 * t] + 1 && d[3 * t + 2] == d[3 * t] + 2) nr = t + 1;
+                    if (nb.usable && d[3 * t] != INT_MIN && d[3 * t + 1] == d[3 * t] + 1 && d[3 * t + 2] == d[3 * t] + 2) nr = t + 1;
                 }
             }
             if (nr == RB) {
@@ -652,6 +673,13 @@ template <typename T, int NV, bool NT>
 static int launch_block(const spmv_hip_matrix *m, const T *x, int64_t ldx, T *y, int64_t ldy, hipStream_t st)
 {
     constexpr int U = NV >= 7 ? 2 : NV >= 5 ? 3 : NV >= 3 ? 4 : 8;
+    // A window sort (SELL-C-sigma, with or without padding) gathers a window's short rows in its last slices: with
+    // windows of 1024 rows that is every 16th slice = every 4th workgroup, and dealt one by one, in even runs or as
+    // contiguous eighths those workgroups all land on the same shader engine of an XCD (8 vectors at C2: 2.2 ms against
+    // 1.85 in runs of 3 or 5).  With several vectors such a handle therefore deals runs of an odd length: its own
+    // block_map where that is one, else 5.
+    const bool windows = NV >= 2 && m->slice_height == kWave && (m->format == SPMV_HIP_SELL_DFC || (m->format == SPMV_HIP_SELL && m->d_row_order));
+    const int map = windows && !(m->block_map >= 3 && (m->block_map & 1)) ? 5 : m->block_map;
     switch (m->format) {
     case SPMV_HIP_CSR_SCALAR:
     case SPMV_HIP_CSR_VECTOR:
@@ -681,30 +709,30 @@ static int launch_block(const spmv_hip_matrix *m, const T *x, int64_t ldx, T *y,
                     if (perm)
                         hipLaunchKernelGGL((sliced64_mv_rows_kernel<T, true, NV, NT>), grid, block, 0, st, m->rows,
                                            m->columns, m->nslices, m->d_slice_ptr, m->d_row_order, diag, m->d_scol, sv, x,
-                                           ldx, y, ldy, m->block_map);
+                                           ldx, y, ldy, map);
                     else
                         hipLaunchKernelGGL((sliced64_mv_rows_kernel<T, false, NV, NT>), grid, block, 0, st, m->rows,
                                            m->columns, m->nslices, m->d_slice_ptr, m->d_row_order, diag, m->d_scol, sv, x,
-                                           ldx, y, ldy, m->block_map);
+                                           ldx, y, ldy, map);
                     break;
                 }
             }
             if (perm)
                 hipLaunchKernelGGL((sliced64_mv_kernel<T, true, NV, U, NT>), grid, block, 0, st, m->rows, m->columns,
                                    m->nslices, m->d_slice_ptr, m->d_row_order, diag, m->d_scol, sv, x,
-                                   ldx, y, ldy, m->block_map);
+                                   ldx, y, ldy, map);
             else
                 hipLaunchKernelGGL((sliced64_mv_kernel<T, false, NV, U, NT>), grid, block, 0, st, m->rows, m->columns,
                                    m->nslices, m->d_slice_ptr, m->d_row_order, diag, m->d_scol, sv, x,
-                                   ldx, y, ldy, m->block_map);
+                                   ldx, y, ldy, map);
         } else {
             const dim3 grid(blocks_for(m->rows, kBlock)), block(kBlock);
             if (perm)
                 hipLaunchKernelGGL((sliced_any_mv_kernel<T, true, NV>), grid, block, 0, st, m->rows, m->slice_height,
-                                   m->d_slice_ptr, m->d_row_order, m->d_scol, sv, x, ldx, y, ldy, m->block_map);
+                                   m->d_slice_ptr, m->d_row_order, m->d_scol, sv, x, ldx, y, ldy, map);
             else
                 hipLaunchKernelGGL((sliced_any_mv_kernel<T, false, NV>), grid, block, 0, st, m->rows, m->slice_height,
-                                   m->d_slice_ptr, m->d_row_order, m->d_scol, sv, x, ldx, y, ldy, m->block_map);
+                                   m->d_slice_ptr, m->d_row_order, m->d_scol, sv, x, ldx, y, ldy, map);
         }
         break;
     }
@@ -712,7 +740,7 @@ static int launch_block(const spmv_hip_matrix *m, const T *x, int64_t ldx, T *y,
         hipLaunchKernelGGL((sell_dfc_mv_kernel<T, NV, (NV >= 5 ? 2 : 4), NT>), dim3(blocks_for(m->nslices, kBlock / kWave)),
                            dim3(kBlock), 0, st, m->rows, m->nslices, m->d_slice_ptr, m->d_sorted_len, m->d_row_order,
                            m->d_vop_ptr, m->d_vop_ptr && m->diag_columns * 2 >= m->vops ? m->d_sdiag : nullptr,
-                           m->d_scol, (const T *)m->d_sval, x, ldx, y, ldy, m->block_map);
+                           m->d_scol, (const T *)m->d_sval, x, ldx, y, ldy, map);
         break;
     default: set_error("unknown format %d", m->format); return 1;
     }
